@@ -1,0 +1,116 @@
+/*
+ * whisper_amd.h — C-ABI of the MI355X-native local-Whisper engine (libwhisper_amd.so).
+ *
+ * The reference (alexk136/whisper) has NO native interface for this path: its boundary is the Python call
+ *   whisper_model = whisper.load_model(WHISPER_MODEL, device=device)   ref:app/transcription/speech_recognition.py:22
+ *   result = whisper_model.transcribe(str(audio_path), **options)      ref:app/transcription/speech_recognition.py:55
+ * into the third-party openai-whisper package.  The entry points below are what a binding for that path binds
+ * instead (ctypes stub: INTEGRATION.md §2); each one names the reference call it replaces.  All functions
+ * return 0 on success and a negative wx_status otherwise, never throw, and record a message retrievable with
+ * wx_last_error().  Pointers named d_* are DEVICE pointers (HBM, on the engine's device); h_* are host
+ * pointers.  `stream` is a hipStream_t passed as void* (NULL = the default stream).  The engine owns weights,
+ * workspace and KV caches; the caller owns every buffer it passes in.  Calls on one engine must not overlap.
+ */
+#ifndef WHISPER_AMD_H
+#define WHISPER_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wx_engine wx_engine;
+
+typedef enum {
+    WX_OK = 0,
+    WX_ERR_INVALID = -1,   /* bad argument / shape / state */
+    WX_ERR_HIP = -2,       /* a HIP runtime call failed */
+    WX_ERR_NOMEM = -3,     /* device allocation failed */
+    WX_ERR_STATE = -4      /* call order violated (e.g. weights not finalized) */
+} wx_status;
+
+enum { WX_PREC_F32 = 0, WX_PREC_BF16 = 1 };
+
+/* Model + runtime configuration.  Dimensions are openai-whisper's ModelDimensions (what
+ * whisper.load_model reads from the checkpoint's "dims", ref:speech_recognition.py:22). */
+typedef struct {
+    int32_t n_mels, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer;
+    int32_t n_vocab, n_text_ctx, n_text_state, n_text_head, n_text_layer;
+    int32_t precision;      /* WX_PREC_F32: every tensor and product in fp32 (token-exact mode);
+                               WX_PREC_BF16: bf16 weights/activations on MFMA, fp32 accumulate + fp32 residual */
+    int32_t max_batch;      /* max 30 s windows per wx_encode / wx_decode call (sizes workspace + caches) */
+    int32_t device;         /* HIP device ordinal */
+    /* special tokens (multilingual layout) */
+    int32_t tok_eot, tok_sot, tok_translate, tok_transcribe, tok_sot_prev, tok_sot_lm;
+    int32_t tok_no_speech, tok_no_timestamps, tok_timestamp_begin, tok_blank;
+} wx_config;
+
+/* Decode options: the subset of openai-whisper DecodingOptions the reference's call can reach
+ * (ref:speech_recognition.py:48-52 passes language/task/fp16 only, so upstream defaults apply). */
+typedef struct {
+    int32_t n_prompt;            /* length of the initial token sequence [.., sot, lang, task, (no_timestamps)] */
+    int32_t sot_index;           /* index of <|startoftranscript|> inside the prompt */
+    int32_t max_new_tokens;      /* upstream sample_len = n_text_ctx / 2 when <= 0 */
+    int32_t without_timestamps;  /* 1: no timestamp rules (prompt ends with <|notimestamps|>) */
+    int32_t suppress_blank;      /* 1 = upstream default */
+    int32_t max_initial_timestamp_index; /* upstream default 50 (1.0 s / 0.02 s); < 0 disables */
+    int32_t use_graph;           /* 1: replay one captured hipGraph per decode step; 0: eager launches */
+    int32_t check_interval;      /* host polls the device-side finished counter every this many steps (>=1) */
+} wx_decode_opts;
+
+const char* wx_last_error(void);
+const char* wx_version(void);
+
+/* replaces whisper.load_model (ref:speech_recognition.py:22): create, upload tensors by canonical
+ * openai name (fp32 host data; converted to the engine precision on device), finalize. */
+int wx_create(const wx_config* cfg, wx_engine** out);
+void wx_destroy(wx_engine* e);
+int wx_set_weight(wx_engine* e, const char* name, const float* h_data, const int64_t* shape, int32_t ndim);
+int wx_set_mel_filters(wx_engine* e, const float* h_filters /* [n_mels][201] */);
+int wx_set_suppress_tokens(wx_engine* e, const int32_t* h_ids, int32_t n);
+int wx_finalize(wx_engine* e);
+
+/* replaces whisper.log_mel_spectrogram inside Whisper.transcribe (ref:speech_recognition.py:55).
+ * Stage 1: frames [frame0, frame0+n_frames) of the file -> d_logmel[m * ld + (f - frame0)] =
+ *          log10(max(mel, 1e-10)), and atomically folds the slice maximum into *d_max (init with wx_mel_reset_max).
+ *          d_pcm holds n_valid samples starting at file sample pcm_offset (halo for a sharded slice); n_total =
+ *          file length + zero padding: samples in [n_file, n_total) read as 0, reflect padding applies at 0 and n_total.
+ * Stage 2: in place max(x, *d_max - 8), (x + 4) / 4 over n_mels x n_frames.
+ * Between the stages a multi-GPU caller all-reduces *d_max with MAX (SURVEY.md §8e caveat 1). */
+int wx_mel_reset_max(wx_engine* e, float* d_max, void* stream);
+int wx_mel_stage1(wx_engine* e, const float* d_pcm, int64_t pcm_offset, int64_t n_valid, int64_t n_file,
+                  int64_t n_total, int64_t frame0, int64_t n_frames, float* d_logmel, int64_t ld,
+                  float* d_max, void* stream);
+int wx_mel_stage2(wx_engine* e, float* d_logmel, int64_t ld, int64_t n_frames, const float* d_max, void* stream);
+
+/* replaces AudioEncoder.forward + the per-layer cross-attention K/V projection (inside model.transcribe,
+ * ref:speech_recognition.py:55).  d_mel: fp32 features, element (w, m, t) at d_mel[w*win_stride + m*row_stride + t]
+ * (contiguous windows: win_stride = n_mels*3000, row_stride = 3000; a whole-file mel [n_mels][ld]: win_stride =
+ * 3000, row_stride = ld).  Frames with w*3000 + t >= n_valid_frames read as 0 (upstream zero-pads the last
+ * segment).  Results stay in the engine
+ * (encoder output + cross K/V cache for slots 0..B-1).  wx_get_encoder_output copies [B][n_audio_ctx][d] fp32. */
+int wx_encode(wx_engine* e, const float* d_mel, int64_t win_stride, int64_t row_stride, int64_t n_valid_frames,
+              int32_t B, void* stream);
+int wx_get_encoder_output(wx_engine* e, int32_t B, float* d_out, void* stream);
+
+/* replaces DecodingTask.run greedy (temperature 0) for the B windows of the last wx_encode.
+ * h_prompt: n_prompt ids shared by all windows.  Outputs (device): d_tokens [B][n_text_ctx] int32 (prompt +
+ * sampled ids, EOT-padded after the end), d_n_tokens [B] (count of sampled ids before EOT), d_sum_logprob [B],
+ * d_no_speech_prob [B].  *h_steps (optional) receives the number of sampling steps executed. */
+int wx_decode_greedy(wx_engine* e, int32_t B, const int32_t* h_prompt, const wx_decode_opts* opts,
+                     int32_t* d_tokens, int32_t* d_n_tokens, float* d_sum_logprob, float* d_no_speech_prob,
+                     int32_t* h_steps, void* stream);
+
+/* replaces TextDecoder.forward (teacher forced): logits of every position of d_tokens [B][n] against the
+ * last wx_encode, written to d_logits [B][n][n_vocab] fp32.  Parity/debug entry point. */
+int wx_decoder_logits(wx_engine* e, int32_t B, const int32_t* d_tokens, int32_t n, float* d_logits, void* stream);
+
+/* introspection for benchmarks: name/launch-count of the dominant kernel and algorithmic byte counts */
+int64_t wx_weight_bytes(wx_engine* e);
+int64_t wx_workspace_bytes(wx_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WHISPER_AMD_H */

@@ -1,0 +1,383 @@
+"""CPU oracle for the local-Whisper hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain PyTorch fp32 restatement of the algorithm behind the reference's
+``whisper_model.transcribe(...)`` call (ref:app/transcription/speech_recognition.py:48-55).  That algorithm
+lives in the third-party package ``openai-whisper`` (declared ``>=20231117``, ref:requirements.txt:26, no lock
+file), which is NOT present in /root/reference, in this container or on the GPU box.  Each function below
+restates the published algorithm and cites the independent port that *is* readable here (``hf:`` =
+transformers 5.15.0) line by line; where the two differ the upstream behaviour is followed and the
+difference is noted.
+
+PARITY PINNING: the reference holds no golden vector, known-answer test or fixture for this path (every
+reference test mocks it) and the dependency itself cannot be run: against openai-whisper
+itself **parity is unpinned**.  What pins this oracle instead: tests/golden/*.npz, produced by
+oracle/make_golden.py from the transformers 5.15.0 Whisper implementation (feature extractor, encoder,
+decoder logits) on seeded weights and seeded audio, and re-checked by tests/test_oracle_vs_golden.py.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.  The product
+(whisper_amd/) never does.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+SAMPLE_RATE = 16000
+N_FFT = 400
+HOP_LENGTH = 160
+CHUNK_LENGTH = 30
+N_SAMPLES = CHUNK_LENGTH * SAMPLE_RATE      # 480000 samples per 30 s window
+N_FRAMES = N_SAMPLES // HOP_LENGTH          # 3000 mel frames per window
+
+
+# -------------------------------------------------------------------------------------------------
+# log-mel front end
+# -------------------------------------------------------------------------------------------------
+
+def _hz_to_mel_slaney(f):
+    """hf:audio_utils.py:470-481 (slaney branch)."""
+    f = np.asarray(f, dtype=np.float64)
+    mels = 3.0 * f / 200.0
+    logstep = 27.0 / np.log(6.4)
+    return np.where(f >= 1000.0, 15.0 + np.log(np.maximum(f, 1e-30) / 1000.0) * logstep, mels)
+
+
+def _mel_to_hz_slaney(m):
+    """hf:audio_utils.py:506-517 (slaney branch)."""
+    m = np.asarray(m, dtype=np.float64)
+    freq = 200.0 * m / 3.0
+    logstep = np.log(6.4) / 27.0
+    return np.where(m >= 15.0, 1000.0 * np.exp(logstep * (m - 15.0)), freq)
+
+
+def mel_filters(n_mels: int) -> np.ndarray:
+    """Slaney-scale, slaney-normalised triangular filterbank, ``[n_mels, 201]`` float32.
+
+    Upstream ships this matrix as ``assets/mel_filters.npz`` (librosa.filters.mel(sr=16000, n_fft=400,
+    n_mels=...)); it is regenerated here, following hf:audio_utils.py:638-729 (centres linear in mel space,
+    triangles in Hz, ``enorm = 2 / (f[i+2] - f[i])``)."""
+    n_freq = 1 + N_FFT // 2
+    fft_freqs = np.linspace(0.0, SAMPLE_RATE // 2, n_freq)
+    mel_pts = np.linspace(_hz_to_mel_slaney(0.0), _hz_to_mel_slaney(8000.0), n_mels + 2)
+    hz_pts = _mel_to_hz_slaney(mel_pts)
+    fdiff = np.diff(hz_pts)
+    slopes = hz_pts[None, :] - fft_freqs[:, None]                  # [n_freq, n_mels + 2]
+    down = -slopes[:, :-2] / fdiff[:-1]
+    up = slopes[:, 2:] / fdiff[1:]
+    fb = np.maximum(0.0, np.minimum(down, up))                     # [n_freq, n_mels]
+    fb *= (2.0 / (hz_pts[2:n_mels + 2] - hz_pts[:n_mels]))[None, :]
+    return np.ascontiguousarray(fb.T).astype(np.float32)
+
+
+def log_mel_spectrogram(audio, n_mels: int, padding: int = 0) -> torch.Tensor:
+    """``[n_mels, n_frames]`` float32, n_frames = (len(audio) + padding) // 160.
+
+    Same steps as hf:models/whisper/feature_extraction_whisper.py:140-165: periodic Hann(400),
+    ``torch.stft(n_fft=400, hop=160, center=True)`` (reflect padding), drop the last frame, |.|², filterbank,
+    ``log10(clamp(1e-10))``, ``max(x, x.max() - 8)``, ``(x + 4) / 4``.  As upstream does (and unlike HF's
+    batched path, :160-162) the max is taken over the WHOLE input, not per 30 s window."""
+    audio = torch.as_tensor(np.asarray(audio), dtype=torch.float32)
+    if padding > 0:
+        audio = F.pad(audio, (0, padding))
+    window = torch.hann_window(N_FFT)
+    stft = torch.stft(audio, N_FFT, HOP_LENGTH, window=window, return_complex=True)
+    magnitudes = stft[..., :-1].abs() ** 2
+    filters = torch.from_numpy(mel_filters(n_mels))
+    mel_spec = filters @ magnitudes
+    log_spec = torch.clamp(mel_spec, min=1e-10).log10()
+    log_spec = torch.maximum(log_spec, log_spec.max() - 8.0)
+    return (log_spec + 4.0) / 4.0
+
+
+def log_mel_unnormalised(audio, n_mels: int) -> torch.Tensor:
+    """The stage-1 quantity ``log10(clamp(mel, 1e-10))`` before the global clamp (used to test the two-stage
+    sharded mel path, SURVEY.md §8e caveat 1)."""
+    audio = torch.as_tensor(np.asarray(audio), dtype=torch.float32)
+    stft = torch.stft(audio, N_FFT, HOP_LENGTH, window=torch.hann_window(N_FFT), return_complex=True)
+    magnitudes = stft[..., :-1].abs() ** 2
+    return torch.clamp(torch.from_numpy(mel_filters(n_mels)) @ magnitudes, min=1e-10).log10()
+
+
+def pad_or_trim_frames(mel: torch.Tensor, length: int = N_FRAMES) -> torch.Tensor:
+    if mel.shape[-1] > length:
+        return mel[..., :length]
+    if mel.shape[-1] < length:
+        return F.pad(mel, (0, length - mel.shape[-1]))
+    return mel
+
+
+def synthetic_audio(seed: int, n_samples: int = N_SAMPLES) -> np.ndarray:
+    """SURVEY.md §8d generator: two sines plus Gaussian noise, float32, ``default_rng(seed)``."""
+    n = np.arange(n_samples, dtype=np.float64)
+    rng = np.random.default_rng(seed)
+    x = 0.3 * np.sin(2 * np.pi * 220.0 * n / SAMPLE_RATE) + 0.2 * np.sin(2 * np.pi * 1330.0 * n / SAMPLE_RATE)
+    x = x + 0.05 * rng.standard_normal(n_samples)
+    return x.astype(np.float32)
+
+
+def varied_audio(seed: int, n_samples: int = N_SAMPLES) -> np.ndarray:
+    """Test signal whose content depends strongly on the seed: three gliding tones with per-second random
+    frequency (80-3500 Hz) and amplitude, plus light noise.  Used by the parity tests so that encoder output and
+    token sequences differ from clip to clip (the §8d benchmark signal differs only in its noise)."""
+    rng = np.random.default_rng(1000 + seed)
+    t = np.arange(n_samples) / float(SAMPLE_RATE)
+    nseg = int(np.ceil(n_samples / SAMPLE_RATE))
+    x = np.zeros(n_samples)
+    for _ in range(3):
+        f = rng.uniform(80.0, 3500.0, nseg + 1)
+        a = rng.uniform(0.0, 0.4, nseg + 1)
+        fi = np.interp(t, np.arange(nseg + 1), f)
+        ai = np.interp(t, np.arange(nseg + 1), a)
+        x += ai * np.sin(2 * np.pi * np.cumsum(fi) / SAMPLE_RATE)
+    x += 0.02 * rng.standard_normal(n_samples)
+    return x.astype(np.float32)
+
+
+# -------------------------------------------------------------------------------------------------
+# model
+# -------------------------------------------------------------------------------------------------
+
+def _layer_norm(x, w, b):
+    return F.layer_norm(x.float(), (x.shape[-1],), w, b, 1e-5)
+
+
+class OracleWhisper:
+    """fp32 encoder/decoder forward on a canonical (openai-named) state dict.
+
+    Encoder: hf:models/whisper/modeling_whisper.py:612-646 (stem :566-567,618-619; layer :391-407).
+    Decoder: hf:...modeling_whisper.py:733-795 (layer :469-503); logits via the tied embedding (:965,1080).
+    Attention: q and k are each scaled by head_dim**-0.25 before the product, the softmax runs in fp32 (upstream
+    ``MultiHeadAttention.qkv_attention`` non-SDPA path; HF scales q only, :304-309 — same value in exact
+    arithmetic).  The key projection has no bias (hf:...:279)."""
+
+    def __init__(self, dims, sd: Dict[str, torch.Tensor]):
+        self.dims = dims
+        self.sd = {k: v.float() for k, v in sd.items()}
+
+    # -- attention ------------------------------------------------------------------------------
+    def _heads(self, x, n_head):
+        B, T, D = x.shape
+        return x.view(B, T, n_head, D // n_head).permute(0, 2, 1, 3)
+
+    def _qkv_attention(self, q, k, v, n_head, mask=None):
+        D = q.shape[-1]
+        scale = (D // n_head) ** -0.25
+        q = self._heads(q, n_head) * scale
+        k = self._heads(k, n_head) * scale
+        v = self._heads(v, n_head)
+        qk = q @ k.transpose(-1, -2)
+        if mask is not None:
+            qk = qk + mask
+        w = F.softmax(qk.float(), dim=-1)
+        out = (w @ v).permute(0, 2, 1, 3).flatten(start_dim=2)
+        return out
+
+    def _lin(self, x, prefix, bias=True):
+        return F.linear(x, self.sd[prefix + ".weight"], self.sd[prefix + ".bias"] if bias else None)
+
+    def _mlp(self, x, p):
+        return self._lin(F.gelu(self._lin(x, p + ".mlp.0")), p + ".mlp.2")
+
+    # -- encoder --------------------------------------------------------------------------------
+    def encode(self, mel: torch.Tensor) -> torch.Tensor:
+        """mel ``[B, n_mels, 3000]`` → ``[B, 1500, d]``."""
+        sd, dims = self.sd, self.dims
+        x = F.gelu(F.conv1d(mel.float(), sd["encoder.conv1.weight"], sd["encoder.conv1.bias"], padding=1))
+        x = F.gelu(F.conv1d(x, sd["encoder.conv2.weight"], sd["encoder.conv2.bias"], stride=2, padding=1))
+        x = x.permute(0, 2, 1)
+        x = x + sd["encoder.positional_embedding"]
+        for i in range(dims.n_audio_layer):
+            p = f"encoder.blocks.{i}"
+            h = _layer_norm(x, sd[p + ".attn_ln.weight"], sd[p + ".attn_ln.bias"])
+            a = self._qkv_attention(self._lin(h, p + ".attn.query"), self._lin(h, p + ".attn.key", bias=False),
+                                    self._lin(h, p + ".attn.value"), dims.n_audio_head)
+            x = x + self._lin(a, p + ".attn.out")
+            x = x + self._mlp(_layer_norm(x, sd[p + ".mlp_ln.weight"], sd[p + ".mlp_ln.bias"]), p)
+        return _layer_norm(x, sd["encoder.ln_post.weight"], sd["encoder.ln_post.bias"])
+
+    # -- decoder --------------------------------------------------------------------------------
+    def cross_kv(self, xa: torch.Tensor):
+        """Per decoder layer (K, V) of the encoder output, computed once per window
+        (hf:...modeling_whisper.py:311-335 cross-KV reuse)."""
+        out = []
+        for i in range(self.dims.n_text_layer):
+            p = f"decoder.blocks.{i}.cross_attn"
+            out.append((self._lin(xa, p + ".key", bias=False), self._lin(xa, p + ".value")))
+        return out
+
+    def decode_step(self, tokens: torch.Tensor, offset: int, cross, self_cache: List) -> torch.Tensor:
+        """Run ``tokens [B, t]`` occupying positions offset..offset+t-1; append to ``self_cache`` (a list of
+        [K, V] per layer, created empty by the caller).  Returns logits ``[B, t, n_vocab]`` float32."""
+        sd, dims = self.sd, self.dims
+        B, t = tokens.shape
+        x = sd["decoder.token_embedding.weight"][tokens] + sd["decoder.positional_embedding"][offset:offset + t]
+        total = offset + t
+        mask = torch.full((total, total), float("-inf")).triu_(1)[offset:total, :total]
+        for i in range(dims.n_text_layer):
+            p = f"decoder.blocks.{i}"
+            h = _layer_norm(x, sd[p + ".attn_ln.weight"], sd[p + ".attn_ln.bias"])
+            k_new = self._lin(h, p + ".attn.key", bias=False)
+            v_new = self._lin(h, p + ".attn.value")
+            if len(self_cache) <= i:
+                self_cache.append([k_new, v_new])
+            else:
+                self_cache[i][0] = torch.cat([self_cache[i][0], k_new], dim=1)
+                self_cache[i][1] = torch.cat([self_cache[i][1], v_new], dim=1)
+            a = self._qkv_attention(self._lin(h, p + ".attn.query"), self_cache[i][0], self_cache[i][1],
+                                    dims.n_text_head, mask)
+            x = x + self._lin(a, p + ".attn.out")
+            h = _layer_norm(x, sd[p + ".cross_attn_ln.weight"], sd[p + ".cross_attn_ln.bias"])
+            ck, cv = cross[i]
+            a = self._qkv_attention(self._lin(h, p + ".cross_attn.query"), ck, cv, dims.n_text_head)
+            x = x + self._lin(a, p + ".cross_attn.out")
+            x = x + self._mlp(_layer_norm(x, sd[p + ".mlp_ln.weight"], sd[p + ".mlp_ln.bias"]), p)
+        x = _layer_norm(x, sd["decoder.ln.weight"], sd["decoder.ln.bias"])
+        return (x @ sd["decoder.token_embedding.weight"].t()).float()
+
+    def logits(self, tokens: torch.Tensor, xa: torch.Tensor) -> torch.Tensor:
+        """Teacher-forced logits for every position of ``tokens [B, t]``."""
+        return self.decode_step(tokens, 0, self.cross_kv(xa), [])
+
+
+# -------------------------------------------------------------------------------------------------
+# decoding rules
+# -------------------------------------------------------------------------------------------------
+
+def suppress_token_ids(tok, non_speech: Sequence[int]) -> List[int]:
+    """Upstream ``DecodingTask._get_suppress_tokens`` with the default ``suppress_tokens="-1"``: the non-speech
+    symbol ids plus [transcribe, translate, sot, sot_prev, sot_lm, no_speech]
+    (hf:generation/logits_process.py:1902-1906 applies the resulting list)."""
+    ids = list(non_speech) + [tok.transcribe, tok.translate, tok.sot, tok.sot_prev, tok.sot_lm, tok.no_speech]
+    return sorted(set(int(i) for i in ids))
+
+
+def initial_tokens(tok, language_index: int, task: str = "transcribe", without_timestamps: bool = True,
+                   prompt_ids: Optional[Sequence[int]] = None, n_text_ctx: int = 448) -> List[int]:
+    """``[sot_prev, prompt…] + [sot, lang, task, (no_timestamps)]`` (hf:models/whisper/generation_whisper.py:1487-1608).
+    The prompt keeps its last ``n_ctx // 2 - 1`` ids, as upstream ``_get_initial_tokens`` does."""
+    seq = [tok.sot, tok.lang(language_index), tok.transcribe if task == "transcribe" else tok.translate]
+    if without_timestamps:
+        seq.append(tok.no_timestamps)
+    if prompt_ids:
+        keep = list(prompt_ids)[-(n_text_ctx // 2 - 1):]
+        seq = [tok.sot_prev] + keep + seq
+    return seq
+
+
+def apply_timestamp_rules(logits: torch.Tensor, tokens: torch.Tensor, sample_begin: int, tok,
+                          max_initial_timestamp_index: Optional[int] = 50) -> None:
+    """In-place timestamp rules, hf:generation/logits_process.py:2000-2047 (same steps as upstream
+    ``ApplyTimestampRules.apply``)."""
+    logits[:, tok.no_timestamps] = -np.inf
+    tb = tok.timestamp_begin
+    for k in range(tokens.shape[0]):
+        seq = tokens[k, sample_begin:].tolist()
+        last_was_ts = len(seq) >= 1 and seq[-1] >= tb
+        penult_was_ts = len(seq) < 2 or seq[-2] >= tb
+        if last_was_ts:
+            if penult_was_ts:
+                logits[k, tb:] = -np.inf
+            else:
+                logits[k, :tok.eot] = -np.inf
+        ts = [s for s in seq if s >= tb]
+        if ts:
+            last = ts[-1] if (last_was_ts and not penult_was_ts) else ts[-1] + 1
+            logits[k, tb:last] = -np.inf
+    if tokens.shape[1] == sample_begin:
+        logits[:, :tb] = -np.inf
+        if max_initial_timestamp_index is not None:
+            logits[:, tb + max_initial_timestamp_index + 1:] = -np.inf
+    logprobs = F.log_softmax(logits.float(), dim=-1)
+    for k in range(tokens.shape[0]):
+        ts_lp = logprobs[k, tb:].logsumexp(dim=-1)
+        max_text = logprobs[k, :tb].max()
+        if ts_lp > max_text:
+            logits[k, :tb] = -np.inf
+
+
+def greedy_decode(model: OracleWhisper, xa: torch.Tensor, init_tokens: Sequence[int], tok,
+                  suppress_ids: Sequence[int], max_new_tokens: Optional[int] = None,
+                  without_timestamps: bool = True, suppress_blank: bool = True) -> Dict[str, object]:
+    """Upstream ``DecodingTask._main_loop`` + ``GreedyDecoder.update`` at temperature 0, no fallback.
+
+    Loop (≤ ``sample_len = n_text_ctx // 2`` steps): logits of the last position → at step 0 the no-speech
+    probability is read from the *unfiltered* softmax at the SOT position (hf:generation/logits_process.py:
+    2091-2112) → SuppressBlank at the first sampled step (hf:...:1859-1866) → SuppressTokens (:1902-1906) →
+    timestamp rules when enabled → argmax; ``sum_logprob`` accumulates log_softmax(filtered)[token] while the
+    sequence has not emitted EOT; finished sequences keep emitting EOT; stop when all are finished.
+
+    Returns tokens (list per sequence, sampled part up to but excluding EOT), sum_logprobs, avg_logprobs
+    (sum / (len + 1), hf:models/whisper/generation_whisper.py:1958-1974), no_speech_probs, and per-step top-1/top-2
+    margins of the filtered logits (used by the fixtures to prove the argmax is well-conditioned)."""
+    dims = model.dims
+    B = xa.shape[0]
+    sample_len = dims.n_text_ctx // 2 if max_new_tokens is None else max_new_tokens
+    init = list(init_tokens)
+    sample_begin = len(init)
+    sot_index = init.index(tok.sot)
+    tokens = torch.tensor([init] * B, dtype=torch.long)
+    cross = model.cross_kv(xa)
+    cache: List = []
+    sum_logprobs = torch.zeros(B)
+    no_speech = torch.zeros(B)
+    margins = []
+    steps = 0
+    for i in range(sample_len):
+        if i == 0:
+            lg_all = model.decode_step(tokens, 0, cross, cache)
+            no_speech = lg_all[:, sot_index].float().softmax(-1)[:, tok.no_speech].clone()
+            lg = lg_all[:, -1].clone()
+        else:
+            lg = model.decode_step(tokens[:, -1:], tokens.shape[1] - 1, cross, cache)[:, -1].clone()
+        if suppress_blank and tokens.shape[1] == sample_begin:
+            lg[:, [tok.blank, tok.eot]] = -np.inf
+        lg[:, list(suppress_ids)] = -np.inf
+        if not without_timestamps:
+            apply_timestamp_rules(lg, tokens, sample_begin, tok)
+        top2 = lg.topk(2, dim=-1).values
+        margins.append((top2[:, 0] - top2[:, 1]).numpy().copy())
+        nxt = lg.argmax(dim=-1)
+        logprobs = F.log_softmax(lg.float(), dim=-1)
+        cur = logprobs[torch.arange(B), nxt]
+        alive = tokens[:, -1] != tok.eot
+        sum_logprobs = sum_logprobs + cur * alive
+        nxt = torch.where(alive, nxt, torch.full_like(nxt, tok.eot))
+        tokens = torch.cat([tokens, nxt[:, None]], dim=-1)
+        steps += 1
+        if bool((tokens[:, -1] == tok.eot).all()) or tokens.shape[-1] > dims.n_text_ctx:
+            break
+    out_tokens = []
+    for b in range(B):
+        seq = tokens[b, sample_begin:].tolist()
+        if tok.eot in seq:
+            seq = seq[:seq.index(tok.eot)]
+        out_tokens.append(seq)
+    avg = [float(sum_logprobs[b]) / (len(out_tokens[b]) + 1) for b in range(B)]
+    return {"tokens": out_tokens, "sum_logprobs": sum_logprobs.numpy(), "avg_logprobs": np.array(avg, np.float32),
+            "no_speech_probs": no_speech.numpy(), "margins": np.stack(margins, axis=0), "steps": steps,
+            "raw_tokens": tokens.numpy()}
+
+
+def transcribe_windows(model: OracleWhisper, audio: np.ndarray, init_tokens: Sequence[int], tok,
+                       suppress_ids: Sequence[int], max_new_tokens: Optional[int] = None,
+                       without_timestamps: bool = True, batch: int = 8) -> Dict[str, object]:
+    """Independent-window long-form variant (a declared divergence from upstream's sequential
+    seek loop): one log-mel over the whole file (+30 s zero padding, global clamp), fixed 3000-frame windows,
+    each window decoded from the same initial tokens with no carry-over."""
+    mel = log_mel_spectrogram(audio, model.dims.n_mels, padding=N_SAMPLES)
+    content_frames = mel.shape[-1] - N_FRAMES
+    n_win = max(1, math.ceil(content_frames / N_FRAMES))
+    # upstream slices mel[:, seek : seek + min(N_FRAMES, content_frames - seek)] and zero-pads to 3000 frames
+    segs = torch.stack([pad_or_trim_frames(mel[:, w * N_FRAMES:min((w + 1) * N_FRAMES, content_frames)])
+                        for w in range(n_win)])
+    toks, sums, nsp = [], [], []
+    for s in range(0, n_win, batch):
+        r = greedy_decode(model, model.encode(segs[s:s + batch]), init_tokens, tok, suppress_ids,
+                          max_new_tokens, without_timestamps)
+        toks += r["tokens"]; sums += list(r["sum_logprobs"]); nsp += list(r["no_speech_probs"])
+    return {"tokens": toks, "sum_logprobs": np.array(sums, np.float32), "no_speech_probs": np.array(nsp, np.float32),
+            "n_windows": n_win, "mel": mel}

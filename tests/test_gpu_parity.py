@@ -1,0 +1,164 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle on identical seeded inputs.
+
+Tolerances (north_star): mel within 1e-4 relative; encoder / logits within the fp32 and bf16 tolerances written
+below; greedy token ids bit-exact in fp32 mode."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import whisper_oracle as wo
+from whisper_amd import checkpoint as ck
+
+pytestmark = pytest.mark.gpu
+
+FP32_TOL = 2e-4     # max |hip - oracle| / max |oracle|, fp32 mode (different summation order only)
+BF16_TOL = 4e-2     # same metric, bf16 weights/activations with fp32 accumulate
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def models():
+    from whisper_amd.engine import WhisperEngine
+    cache = {}
+
+    def get(name, precision, max_batch=4, **kw):
+        key = (name, precision, max_batch, tuple(sorted(kw.items())))
+        if key not in cache:
+            dims = ck.dims_for(name)
+            sd = ck.synthetic_state_dict(dims, seed=0, **kw)
+            cache[key] = (dims, sd, WhisperEngine(dims, sd, precision=precision, max_batch=max_batch))
+        return cache[key]
+
+    yield get
+    for _, _, e in cache.values():
+        e.close()
+
+
+@pytest.mark.parametrize("n_mels", [80, 128])
+@pytest.mark.parametrize("n_samples", [wo.N_SAMPLES, 100000, 16000 * 47 + 123])
+def test_mel_parity(models, n_mels, n_samples):
+    # the front end depends only on n_mels: micro has 80 bins, micro128 the large-v3 128-bin filterbank
+    name = "micro" if n_mels == 80 else "micro128"
+    dims, sd, eng = models(name, "fp32")
+    audio = wo.synthetic_audio(3, n_samples)
+    ref = wo.log_mel_spectrogram(audio, n_mels, padding=wo.N_SAMPLES).numpy()
+    got = eng.log_mel(torch.from_numpy(audio)).cpu().numpy()
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) < 1e-4
+
+
+def test_mel_two_stage_matches_sharded_max(models):
+    """Stage 1 on two halves + MAX of the two maxima + stage 2 == single pass (SURVEY.md §8e caveat 1)."""
+    dims, sd, eng = models("micro", "fp32")
+    audio = wo.synthetic_audio(5, 16000 * 75)
+    audio[: 16000 * 30] *= 0.05            # make the global max live in the second half
+    pcm = torch.from_numpy(audio).cuda()
+    whole = eng.log_mel(pcm)
+    n_file = pcm.numel(); n_total = n_file + wo.N_SAMPLES; n_frames = n_total // 160
+    out = torch.empty((dims.n_mels, n_frames), device="cuda")
+    g1 = torch.empty(1, device="cuda"); g2 = torch.empty(1, device="cuda")
+    eng.reset_max(g1); eng.reset_max(g2)
+    half = (n_frames // 2)
+    s_lo = max(0, half * 160 - 200)
+    eng.mel_stage1(pcm[: half * 160 + 400].contiguous(), 0, n_file, n_total, 0, half, out, g1)
+    eng.mel_stage1(pcm[s_lo:].contiguous(), s_lo, n_file, n_total, half, n_frames - half, out[:, half:], g2)
+    g = torch.maximum(g1, g2)
+    eng.mel_stage2(out, n_frames, g)
+    assert torch.equal(out, whole)
+
+
+@pytest.mark.parametrize("name,precision,tol", [("micro", "fp32", FP32_TOL), ("tiny", "fp32", FP32_TOL),
+                                                ("micro", "bf16", BF16_TOL), ("tiny", "bf16", BF16_TOL)])
+def test_encoder_and_logits_parity(models, name, precision, tol):
+    dims, sd, eng = models(name, precision)
+    om = wo.OracleWhisper(dims, sd)
+    mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(s), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000] for s in (0, 1)])
+    with torch.no_grad():
+        xa = om.encode(mels)
+    eng.encode_windows(mels)
+    got = eng.encoder_output(2).cpu()
+    assert rel_err(got, xa) < tol
+    tok = eng.tok
+    toks = torch.tensor([[tok.sot, tok.lang(0), tok.transcribe, tok.no_timestamps, 100, 2000, 31337],
+                         [tok.sot, tok.lang(3), tok.transcribe, tok.no_timestamps, 7, 50000, 421]])
+    with torch.no_grad():
+        ref = om.logits(toks, xa)
+    lg = eng.decoder_logits(toks).cpu()
+    assert lg.shape == ref.shape
+    assert rel_err(lg, ref) < tol
+
+
+@pytest.mark.parametrize("name", ["micro", "tiny"])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_greedy_tokens_bit_exact_fp32(models, name, use_graph):
+    dims, sd, eng = models(name, "fp32", eot_boost=3.0)
+    om = wo.OracleWhisper(dims, sd)
+    tok = eng.tok
+    mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(s), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000] for s in range(4)])
+    init = wo.initial_tokens(tok, 0)
+    with torch.no_grad():
+        ref = wo.greedy_decode(om, om.encode(mels), init, tok, wo.suppress_token_ids(tok, ck.non_speech_suppress_ids()), max_new_tokens=40)
+    eng.encode_windows(mels)
+    r = eng.decode_greedy(4, init, max_new_tokens=40, use_graph=use_graph, check_interval=4)
+    t, n = r["tokens"].cpu(), r["n_tokens"].cpu()
+    got = [t[b, len(init):len(init) + int(n[b])].tolist() for b in range(4)]
+    assert ref["margins"].min() > 1e-3, "fixture argmax is ill-conditioned; pick another seed"
+    assert got == ref["tokens"]
+    np.testing.assert_allclose(r["sum_logprobs"].cpu().numpy(), ref["sum_logprobs"], rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(r["no_speech_probs"].cpu().numpy(), ref["no_speech_probs"], rtol=1e-3)
+    assert (t[:, :len(init)] == torch.tensor(init)).all()
+    for b in range(4):                       # rows are EOT-padded after the end
+        assert (t[b, len(init) + int(n[b]):] == tok.eot).all()
+
+
+def test_greedy_with_timestamp_rules_fp32(models):
+    dims, sd, eng = models("micro", "fp32", eot_boost=3.0)
+    om = wo.OracleWhisper(dims, sd)
+    tok = eng.tok
+    mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(s), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000] for s in range(3)])
+    init = wo.initial_tokens(tok, 0, without_timestamps=False)
+    with torch.no_grad():
+        ref = wo.greedy_decode(om, om.encode(mels), init, tok, wo.suppress_token_ids(tok, ck.non_speech_suppress_ids()),
+                               max_new_tokens=48, without_timestamps=False)
+    eng.encode_windows(mels)
+    r = eng.decode_greedy(3, init, max_new_tokens=48, without_timestamps=False)
+    t, n = r["tokens"].cpu(), r["n_tokens"].cpu()
+    got = [t[b, len(init):len(init) + int(n[b])].tolist() for b in range(3)]
+    assert got == ref["tokens"]
+    assert all(g[0] >= tok.timestamp_begin for g in got if g)   # first sampled token must be a timestamp
+    np.testing.assert_allclose(r["sum_logprobs"].cpu().numpy(), ref["sum_logprobs"], rtol=1e-4, atol=1e-3)
+
+
+def test_long_form_matches_oracle_fp32(models):
+    dims, sd, eng = models("micro", "fp32", max_batch=2, eot_boost=3.0)
+    om = wo.OracleWhisper(dims, sd)
+    tok = eng.tok
+    audio = wo.varied_audio(11, 16000 * 70 + 777)       # 3 windows, the last one ragged
+    init = wo.initial_tokens(tok, 0)
+    with torch.no_grad():
+        ref = wo.transcribe_windows(om, audio, init, tok, wo.suppress_token_ids(tok, ck.non_speech_suppress_ids()), max_new_tokens=24)
+    r = eng.transcribe_pcm(audio, init, max_new_tokens=24)
+    assert r["n_windows"] == ref["n_windows"] == 3
+    assert r["tokens"] == ref["tokens"]
+
+
+def test_bf16_greedy_agrees_with_oracle_where_margin_is_large(models):
+    dims, sd, eng = models("tiny", "bf16")
+    om = wo.OracleWhisper(dims, sd)
+    tok = eng.tok
+    mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(s), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000] for s in range(2)])
+    init = wo.initial_tokens(tok, 0)
+    with torch.no_grad():
+        ref = wo.greedy_decode(om, om.encode(mels), init, tok, wo.suppress_token_ids(tok, ck.non_speech_suppress_ids()), max_new_tokens=16)
+    eng.encode_windows(mels)
+    r = eng.decode_greedy(2, init, max_new_tokens=16)
+    t = r["tokens"].cpu()
+    for b in range(2):
+        for i, want in enumerate(ref["tokens"][b]):
+            if ref["margins"][i, b] < 0.15:      # bf16 logits move by O(1e-2): stop comparing at the first close call
+                break
+            assert int(t[b, len(init) + i]) == want

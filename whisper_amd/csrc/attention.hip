@@ -1,0 +1,360 @@
+// attention.hip — streaming attention kernels for gfx950.
+//
+// attn_decode  one query per (batch, head): decoder self-attention over the paged KV cache and decoder
+//              cross-attention over the cached encoder K/V (SURVEY.md §7 `attn_dec_self`, `attn_dec_cross` — the
+//              dominant decode cost: 2*1500*64*sizeof(T) bytes per (b, h) per layer per step, read exactly once).
+//              HBM-bound by construction: every wave-instruction is one fully coalesced 1 KiB load (64 lanes x 16 B),
+//              16 of them in flight per wave, no LDS staging (the data has no reuse), dot products reduced inside
+//              8-lane (bf16) / 16-lane (fp32) groups with DPP, one independent online-softmax stream per lane group
+//              so the key loop has no cross-lane max and no barrier.
+// attn_rows    same lane mapping, NQ queries per wave sharing each K/V load: fp32 encoder attention ("token-exact"
+//              mode) and the reference implementation the MFMA flash kernel is tested against.
+#include "common.h"
+
+namespace wx {
+
+template <typename T> struct Chunk;
+template <> struct Chunk<float> {
+    static constexpr int EPL = 4;
+    typedef f32x4 Raw;
+    static __device__ __forceinline__ void unpack(const Raw& r, float* f) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = r[j];
+    }
+    static __device__ __forceinline__ Raw pack(const float* f) { return Raw{f[0], f[1], f[2], f[3]}; }
+};
+template <> struct Chunk<bf16> {
+    static constexpr int EPL = 8;
+    typedef bf16x8 Raw;
+    static __device__ __forceinline__ void unpack(const Raw& r, float* f) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (float)r[j];
+    }
+    static __device__ __forceinline__ Raw pack(const float* f) {
+        Raw r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (bf16)f[j];
+        return r;
+    }
+};
+
+template <int CTRL> __device__ __forceinline__ float dpp_move(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+// sum over aligned groups of LPK lanes, result in every lane of the group
+template <int LPK> __device__ __forceinline__ float group_sum(float x) {
+    x += dpp_move<0xB1>(x);    // quad_perm [1,0,3,2]
+    x += dpp_move<0x4E>(x);    // quad_perm [2,3,0,1]
+    x += dpp_move<0x141>(x);   // row_half_mirror: joins the two quads of 8 lanes
+    if (LPK == 16) x += dpp_move<0x140>(x);   // row_mirror: joins the two halves of 16 lanes
+    return x;
+}
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+// merge two online-softmax states (m, l, o[]) <- (m2, l2, o2[])
+template <int E> __device__ __forceinline__ void merge_state(float& m, float& l, float* o, float m2, float l2, const float* o2) {
+    const float mn = fmaxf(m, m2);
+    const float a = (m == -INFINITY) ? 0.f : exp2f((m - mn) * LOG2E);
+    const float b = (m2 == -INFINITY) ? 0.f : exp2f((m2 - mn) * LOG2E);
+    l = l * a + l2 * b;
+#pragma unroll
+    for (int e = 0; e < E; ++e) o[e] = o[e] * a + o2[e] * b;
+    m = mn;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// decode: one query per (b, h)
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, bool PAGED>
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
+    typedef Chunk<T> C;
+    constexpr int EPL = C::EPL, LPK = HEAD_DIM / EPL, KPI = 64 / LPK, U = 8, IT = KPI * U;
+    __shared__ float s_m[4], s_l[4];
+    __shared__ float s_o[4][HEAD_DIM];
+    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H, split = blockIdx.y;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int sub = lane % LPK, grp = lane / LPK;
+    const int t_cur = a.d_pos ? *a.d_pos : -1;
+    const int n_keys = a.d_pos ? t_cur + 1 : a.n_keys;
+
+    float qf[EPL];
+    {
+        const T* qp = reinterpret_cast<const T*>(a.Q) + (int64_t)b * a.q_sb + h * a.q_sh + sub * EPL;
+        C::unpack(*reinterpret_cast<const typename C::Raw*>(qp), qf);
+    }
+    const T* knew = nullptr; const T* vnew = nullptr;
+    if (PAGED) {
+        knew = reinterpret_cast<const T*>(a.Knew) + (int64_t)b * a.new_sb + h * HEAD_DIM + sub * EPL;
+        vnew = reinterpret_cast<const T*>(a.Vnew) + (int64_t)b * a.new_sb + h * HEAD_DIM + sub * EPL;
+        if (split == 0 && wid == 0 && lane < LPK) {
+            // append this step's key/value row to the page of position t_cur
+            const int page = a.page_table[b * a.pt_ld + t_cur / KV_PAGE];
+            const int64_t off = (((int64_t)page * a.H + h) * KV_PAGE + t_cur % KV_PAGE) * HEAD_DIM + sub * EPL;
+            *reinterpret_cast<typename C::Raw*>(reinterpret_cast<T*>(a.Kpool) + off) = *reinterpret_cast<const typename C::Raw*>(knew);
+            *reinterpret_cast<typename C::Raw*>(reinterpret_cast<T*>(a.Vpool) + off) = *reinterpret_cast<const typename C::Raw*>(vnew);
+        }
+    }
+    const T* kbase = nullptr; const T* vbase = nullptr;
+    if (!PAGED) {
+        kbase = reinterpret_cast<const T*>(a.K) + ((int64_t)b * a.H + h) * a.kv_sbh + sub * EPL;
+        vbase = reinterpret_cast<const T*>(a.V) + ((int64_t)b * a.H + h) * a.kv_sbh + sub * EPL;
+    }
+    const int total_it = (n_keys + IT - 1) / IT;
+    const int it0 = (int)((int64_t)split * total_it / a.n_split), it1 = (int)((int64_t)(split + 1) * total_it / a.n_split);
+
+    float m = -INFINITY, l = 0.f, o[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) o[e] = 0.f;
+
+    for (int it = it0 + wid; it < it1; it += 4) {
+        typename C::Raw kr[U], vr[U];
+        const int key0 = it * IT + grp;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int key = key0 + u * KPI;
+            if (key > n_keys - 1) key = n_keys - 1;
+            const T* kp; const T* vp;
+            if (PAGED) {
+                if (key == t_cur) { kp = knew; vp = vnew; }
+                else {
+                    const int page = a.page_table[b * a.pt_ld + key / KV_PAGE];
+                    const int64_t off = (((int64_t)page * a.H + h) * KV_PAGE + key % KV_PAGE) * HEAD_DIM + sub * EPL;
+                    kp = reinterpret_cast<const T*>(a.Kpool) + off;
+                    vp = reinterpret_cast<const T*>(a.Vpool) + off;
+                }
+            } else {
+                kp = kbase + (int64_t)key * HEAD_DIM;
+                vp = vbase + (int64_t)key * HEAD_DIM;
+            }
+            kr[u] = __builtin_nontemporal_load(reinterpret_cast<const typename C::Raw*>(kp));
+            vr[u] = __builtin_nontemporal_load(reinterpret_cast<const typename C::Raw*>(vp));
+        }
+        float s[U];
+        float mt = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float kf[EPL];
+            C::unpack(kr[u], kf);
+            float d = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) d = fmaf(qf[e], kf[e], d);
+            d = group_sum<LPK>(d);
+            s[u] = (key0 + u * KPI < n_keys) ? d : -INFINITY;
+            mt = fmaxf(mt, s[u]);
+        }
+        if (mt > -INFINITY) {
+            const float mn = fmaxf(m, mt);
+            const float alpha = (m == -INFINITY) ? 0.f : exp2f((m - mn) * LOG2E);
+            l *= alpha;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) o[e] *= alpha;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float p = exp2f((s[u] - mn) * LOG2E);   // exp2(-inf) = 0 for masked keys
+                l += p;
+                float vf[EPL];
+                C::unpack(vr[u], vf);
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) o[e] = fmaf(p, vf[e], o[e]);
+            }
+            m = mn;
+        }
+    }
+    // merge the KPI lane groups of the wave (lanes that hold the same 16-B chunk of the head)
+#pragma unroll
+    for (int off = LPK; off < 64; off <<= 1) {
+        const float m2 = __shfl_xor(m, off), l2 = __shfl_xor(l, off);
+        float o2[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o2[e] = __shfl_xor(o[e], off);
+        merge_state<EPL>(m, l, o, m2, l2, o2);
+    }
+    if (lane < LPK) {
+        if (lane == 0) { s_m[wid] = m; s_l[wid] = l; }
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) s_o[wid][sub * EPL + e] = o[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < HEAD_DIM) {
+        const int d = threadIdx.x;
+        float M = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+        float L = 0.f, acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float f = (s_m[w] == -INFINITY) ? 0.f : exp2f((s_m[w] - M) * LOG2E);
+            L += s_l[w] * f;
+            acc += s_o[w][d] * f;
+        }
+        if (a.n_split == 1) {
+            T* op = reinterpret_cast<T*>(a.O) + (int64_t)b * a.o_sb + h * a.o_sh + d;
+            *op = (T)(acc / L);
+        } else {
+            float* pp = a.partial + ((int64_t)blockIdx.x * a.n_split + split) * (HEAD_DIM + 2);
+            pp[d] = acc;
+            if (d == 0) { pp[HEAD_DIM] = M; pp[HEAD_DIM + 1] = L; }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void attn_decode_combine_kernel(AttnArgs a) {
+    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H, d = threadIdx.x;
+    const float* pp = a.partial + (int64_t)blockIdx.x * a.n_split * (HEAD_DIM + 2);
+    float M = -INFINITY;
+    for (int s = 0; s < a.n_split; ++s) M = fmaxf(M, pp[s * (HEAD_DIM + 2) + HEAD_DIM]);
+    float L = 0.f, acc = 0.f;
+    for (int s = 0; s < a.n_split; ++s) {
+        const float ms = pp[s * (HEAD_DIM + 2) + HEAD_DIM];
+        const float f = (ms == -INFINITY) ? 0.f : exp2f((ms - M) * LOG2E);
+        L += pp[s * (HEAD_DIM + 2) + HEAD_DIM + 1] * f;
+        acc += pp[s * (HEAD_DIM + 2) + d] * f;
+    }
+    T* op = reinterpret_cast<T*>(a.O) + (int64_t)b * a.o_sb + h * a.o_sh + d;
+    *op = (T)(acc / L);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// rows: NQ queries per wave, all keys, dense non-causal
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, int NQ, int U>
+__global__ __launch_bounds__(256) void attn_rows_kernel(AttnArgs a) {
+    typedef Chunk<T> C;
+    constexpr int EPL = C::EPL, LPK = HEAD_DIM / EPL, KPI = 64 / LPK, IT = KPI * U;
+    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int sub = lane % LPK, grp = lane / LPK;
+    const int iq0 = (blockIdx.y * 4 + wid) * NQ;
+    if (iq0 >= a.n_q) return;
+    const int n_keys = a.n_keys;
+    float qf[NQ][EPL];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        int iq = iq0 + q; if (iq > a.n_q - 1) iq = a.n_q - 1;
+        const T* qp = reinterpret_cast<const T*>(a.Q) + (int64_t)b * a.q_sb + (int64_t)iq * a.q_sq + h * a.q_sh + sub * EPL;
+        C::unpack(*reinterpret_cast<const typename C::Raw*>(qp), qf[q]);
+    }
+    const T* kbase = reinterpret_cast<const T*>(a.K) + ((int64_t)b * a.H + h) * a.kv_sbh + sub * EPL;
+    const T* vbase = reinterpret_cast<const T*>(a.V) + ((int64_t)b * a.H + h) * a.kv_sbh + sub * EPL;
+    float m[NQ], l[NQ], o[NQ][EPL];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        m[q] = -INFINITY; l[q] = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o[q][e] = 0.f;
+    }
+    const int total_it = (n_keys + IT - 1) / IT;
+    for (int it = 0; it < total_it; ++it) {
+        typename C::Raw kr[U], vr[U];
+        const int key0 = it * IT + grp;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int key = key0 + u * KPI;
+            if (key > n_keys - 1) key = n_keys - 1;
+            kr[u] = *reinterpret_cast<const typename C::Raw*>(kbase + (int64_t)key * HEAD_DIM);
+            vr[u] = *reinterpret_cast<const typename C::Raw*>(vbase + (int64_t)key * HEAD_DIM);
+        }
+        float s[NQ][U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float kf[EPL];
+            C::unpack(kr[u], kf);
+            const bool valid = key0 + u * KPI < n_keys;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) d = fmaf(qf[q][e], kf[e], d);
+                d = group_sum<LPK>(d);
+                s[q][u] = valid ? d : -INFINITY;
+            }
+        }
+        float vf[U][EPL];
+#pragma unroll
+        for (int u = 0; u < U; ++u) C::unpack(vr[u], vf[u]);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            float mt = s[q][0];
+#pragma unroll
+            for (int u = 1; u < U; ++u) mt = fmaxf(mt, s[q][u]);
+            if (mt > -INFINITY) {
+                const float mn = fmaxf(m[q], mt);
+                const float alpha = (m[q] == -INFINITY) ? 0.f : exp2f((m[q] - mn) * LOG2E);
+                l[q] *= alpha;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) o[q][e] *= alpha;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float p = exp2f((s[q][u] - mn) * LOG2E);
+                    l[q] += p;
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) o[q][e] = fmaf(p, vf[u][e], o[q][e]);
+                }
+                m[q] = mn;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+        for (int off = LPK; off < 64; off <<= 1) {
+            const float m2 = __shfl_xor(m[q], off), l2 = __shfl_xor(l[q], off);
+            float o2[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) o2[e] = __shfl_xor(o[q][e], off);
+            merge_state<EPL>(m[q], l[q], o[q], m2, l2, o2);
+        }
+        const int iq = iq0 + q;
+        if (lane < LPK && iq < a.n_q) {
+            float r[EPL];
+            const float inv = 1.0f / l[q];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) r[e] = o[q][e] * inv;
+            T* op = reinterpret_cast<T*>(a.O) + (int64_t)b * a.o_sb + (int64_t)iq * a.o_sq + h * a.o_sh + sub * EPL;
+            *reinterpret_cast<typename C::Raw*>(op) = C::pack(r);
+        }
+    }
+}
+
+static int check_common(const AttnArgs& a) {
+    if (a.B <= 0 || a.H <= 0 || !a.Q || !a.O) return -1;
+    const size_t es = dtype_size(a.dt);
+    if ((a.q_sb * es) % 16 || (a.q_sq * es) % 16 || (a.q_sh * es) % 16 || (a.o_sb * es) % 16 || (a.o_sq * es) % 16 || (a.o_sh * es) % 16 || (a.kv_sbh * es) % 16 || (a.new_sb * es) % 16) return -1;
+    return 0;
+}
+
+int launch_attn_decode(const AttnArgs& a, hipStream_t st) {
+    if (check_common(a)) return -1;
+    if (a.n_q != 1 || a.n_split < 1) return -1;
+    const bool paged = a.page_table != nullptr;
+    if (paged && (!a.d_pos || !a.Kpool || !a.Vpool || !a.Knew || !a.Vnew)) return -1;
+    if (!paged && (!a.K || !a.V || a.n_keys <= 0)) return -1;
+    if (a.n_split > 1 && !a.partial) return -1;
+    dim3 grid(a.B * a.H, a.n_split), block(256);
+    if (a.dt == DT_BF16) {
+        if (paged) hipLaunchKernelGGL((attn_decode_kernel<bf16, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((attn_decode_kernel<bf16, false>), grid, block, 0, st, a);
+        if (a.n_split > 1) hipLaunchKernelGGL(attn_decode_combine_kernel<bf16>, dim3(a.B * a.H), dim3(64), 0, st, a);
+    } else {
+        if (paged) hipLaunchKernelGGL((attn_decode_kernel<float, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((attn_decode_kernel<float, false>), grid, block, 0, st, a);
+        if (a.n_split > 1) hipLaunchKernelGGL(attn_decode_combine_kernel<float>, dim3(a.B * a.H), dim3(64), 0, st, a);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_attn_rows(const AttnArgs& a, hipStream_t st) {
+    if (check_common(a)) return -1;
+    if (!a.K || !a.V || a.n_keys <= 0 || a.n_q <= 0) return -1;
+    constexpr int NQ = 4;
+    dim3 grid(a.B * a.H, (a.n_q + 4 * NQ - 1) / (4 * NQ)), block(256);
+    if (a.dt == DT_BF16) hipLaunchKernelGGL((attn_rows_kernel<bf16, NQ, 4>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((attn_rows_kernel<float, NQ, 4>), grid, block, 0, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+#ifndef WX_HAVE_FLASH
+int launch_attn_flash_bf16(const AttnArgs&, hipStream_t) { return -100; }   // -100 = not built; caller falls back to attn_rows
+#endif
+
+}  // namespace wx

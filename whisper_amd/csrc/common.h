@@ -1,0 +1,135 @@
+// common.h — shared types and launcher declarations for the gfx950 Whisper engine.
+// Everything here targets CDNA4 (wave64, MFMA, 160 KB LDS) only; there is no other back end.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wx {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+enum DType : int { DT_F32 = 0, DT_BF16 = 1 };
+static inline size_t dtype_size(int dt) { return dt == DT_F32 ? 4 : 2; }
+
+constexpr int HEAD_DIM = 64;      // every Whisper size uses 64-wide heads
+constexpr int KV_PAGE = 16;       // tokens per page of the decoder self-attention KV cache
+constexpr int N_FFT = 400;
+constexpr int HOP = 160;
+constexpr int N_FREQ = 201;
+constexpr int WIN_FRAMES = 3000;  // mel frames per 30 s window
+
+// ---- GEMM -------------------------------------------------------------------------------------------
+// out[m][n] = epilogue( sum_k A[m][k] * W[n][k] ), A rows addressed as
+//   A + (m / a_rows_per_batch) * a_batch_stride + (m % a_rows_per_batch) * lda      (elements)
+// which makes a k=3 convolution over a zero-padded [T+2][C] activation an ordinary GEMM (lda = stride*C, K = 3C).
+struct GemmEpilogue {
+    const float* bias = nullptr;        // [N]
+    int act = 0;                        // 1: exact-erf GELU
+    const float* residual = nullptr;    // fp32 [M][ldr], added after activation
+    int64_t ldr = 0;
+    const float* rowadd = nullptr;      // fp32 [rowadd_period][N] added per (m % period) (encoder positional table)
+    int rowadd_period = 0;
+    int colscale_period = 0;            // v *= colscale[n / period] (q/k pre-scaling by head_dim^-0.25)
+    float colscale[3] = {1.f, 1.f, 1.f};
+    int mode = 0;                       // 0: row-major out[m*ldo + n]; 1: head split (below)
+    void* out = nullptr;
+    int out_dtype = DT_F32;
+    int64_t ldo = 0;
+    // row-major with per-batch row remap: out row = (m / rows_per_batch) * out_batch_rows + out_row_offset + m % rows_per_batch
+    int out_rows_per_batch = 0;         // 0 = no remap
+    int64_t out_batch_rows = 0, out_row_offset = 0;
+    // head split: column n -> split s = n / hs_d, head h = (n % hs_d) / 64, c = n % 64; row m -> (b, t) = (m / hs_T, m % hs_T)
+    // element goes to out_split[s][((b * hs_H + h) * hs_T + t) * 64 + c]
+    void* out_split[3] = {nullptr, nullptr, nullptr};
+    int hs_T = 0, hs_H = 0, hs_d = 0;
+};
+
+struct GemmArgs {
+    const void* A = nullptr;
+    int64_t lda = 0, a_rows_per_batch = 0, a_batch_stride = 0;
+    const void* W = nullptr;
+    int64_t ldw = 0;
+    int M = 0, N = 0, K = 0;
+    int in_dtype = DT_F32;              // dtype of A and W
+    GemmEpilogue ep;
+};
+// Returns 0 or a negative wx_status. Chooses the kernel from (dtype, M).
+int launch_gemm(const GemmArgs& g, hipStream_t st);
+
+// ---- elementwise / norms ---------------------------------------------------------------------------
+int launch_layernorm(const float* x, const float* gamma, const float* beta, void* out, int out_dtype,
+                     int rows, int d, hipStream_t st);
+// x[b][:] = tok_emb[tokens[b*ld_tok + *d_pos]][:] + pos_emb[*d_pos][:]   (fp32 out; embedding tables in `dt`)
+int launch_embed(const void* tok_emb, const void* pos_emb, int dt, const int32_t* tokens, int ld_tok,
+                 const int32_t* d_pos, float* x, int B, int d, hipStream_t st);
+int launch_convert_f32(const float* in, void* out, int out_dtype, int64_t n, hipStream_t st);
+int launch_to_f32(const void* in, int in_dtype, float* out, int64_t n, hipStream_t st);
+// mel (w, m, t) -> conv input xpad[w][1 + t][c_pad] (dtype dt); zero rows 0 and T+1, zero channels >= n_mels,
+// zero for global frame w*3000 + t >= n_valid_frames.
+int launch_mel_to_conv_input(const float* mel, int64_t win_stride, int64_t row_stride, int64_t n_valid_frames,
+                             void* xpad, int dt, int B, int n_mels, int c_pad, hipStream_t st);
+int launch_zero_pad_rows(void* xpad, int dt, int B, int rows_per_batch, int C, hipStream_t st);
+
+// ---- mel front end ------------------------------------------------------------------------------------
+struct MelTables {                       // device tables built at wx_finalize
+    const float* window = nullptr;       // [400] periodic Hann
+    const float* cs = nullptr;           // [400][2] cos, sin of 2*pi*i/400
+    const float* filters = nullptr;      // [n_mels][201]
+    const int32_t* frange = nullptr;     // [n_mels][2] first/last+1 non-zero bin of each filter
+    int n_mels = 0;
+};
+int launch_mel_stage1(const MelTables& t, const float* pcm, int64_t pcm_offset, int64_t n_valid, int64_t n_file,
+                      int64_t n_total, int64_t frame0, int64_t n_frames, float* out, int64_t ld, float* d_max,
+                      hipStream_t st);
+int launch_mel_stage2(float* x, int64_t ld, int n_mels, int64_t n_frames, const float* d_max, hipStream_t st);
+int launch_fill_f32(float* p, float v, int64_t n, hipStream_t st);
+
+// ---- attention ----------------------------------------------------------------------------------------
+struct AttnArgs {
+    int dt = DT_F32;
+    // queries: q(b, iq, h) at Q + b*q_sb + iq*q_sq + h*q_sh
+    const void* Q = nullptr; int64_t q_sb = 0, q_sq = 0, q_sh = HEAD_DIM;
+    int n_q = 1;                         // queries per (b, h)
+    // dense keys/values: K + (b*H + h)*kv_sbh + t*64
+    const void* K = nullptr; const void* V = nullptr; int64_t kv_sbh = 0;
+    int n_keys = 0;                      // dense key count (ignored when d_pos != nullptr)
+    // paged self-attention cache (decoder): page_table[b*pt_ld + t/KV_PAGE] -> page p; row at ((p*H + h)*KV_PAGE + t%KV_PAGE)*64
+    const int32_t* page_table = nullptr; int pt_ld = 0;
+    void* Kpool = nullptr; void* Vpool = nullptr;   // written at position *d_pos with the new token's k/v
+    const void* Knew = nullptr; const void* Vnew = nullptr; int64_t new_sb = 0;  // k/v of the current token: + b*new_sb + h*64
+    const int32_t* d_pos = nullptr;      // device scalar: current position t (keys 0..t are attended)
+    // output o(b, iq, h) at O + b*o_sb + iq*o_sq + h*o_sh
+    void* O = nullptr; int64_t o_sb = 0, o_sq = 0, o_sh = HEAD_DIM;
+    int B = 0, H = 0;
+    // split-key workspace (used when few (b,h) pairs would leave the chip idle)
+    float* partial = nullptr; int n_split = 1;
+};
+int launch_attn_decode(const AttnArgs& a, hipStream_t st);     // n_q == 1, waves split the keys
+int launch_attn_rows(const AttnArgs& a, hipStream_t st);       // many queries, non-causal, dense K/V (fp32 encoder path)
+int launch_attn_flash_bf16(const AttnArgs& a, hipStream_t st); // MFMA flash attention, dense bf16 K/V, non-causal
+
+// ---- sampler ------------------------------------------------------------------------------------------
+struct SamplerArgs {
+    const float* logits = nullptr; int64_t ldl = 0; int n_vocab = 0;
+    int32_t* tokens = nullptr; int ld_tok = 0;     // [B][n_text_ctx]
+    int32_t* d_pos = nullptr;                      // incremented by the last block
+    int32_t* d_block_counter = nullptr;            // zero-initialised scratch counter
+    const uint8_t* suppress = nullptr;             // [n_vocab] 1 = masked
+    float* sum_logprob = nullptr; float* no_speech = nullptr;
+    int32_t* n_finished = nullptr;                 // device counter of sequences that have emitted EOT
+    int B = 0, n_prompt = 0, sot_index = 0;
+    int tok_eot = 0, tok_blank = 0, tok_no_speech = 0, tok_no_timestamps = 0, tok_timestamp_begin = 0;
+    int without_timestamps = 1, suppress_blank = 1, max_initial_ts = 50;
+    int forced = 0;                                // 1: teacher forcing, tokens are never written
+};
+int launch_sampler(const SamplerArgs& s, hipStream_t st);
+int launch_finish_tokens(int32_t* tokens, int ld_tok, int n_prompt, int tok_eot, const int32_t* d_pos, int32_t* n_tokens,
+                         int B, hipStream_t st);
+
+}  // namespace wx

@@ -1,0 +1,328 @@
+// elementwise.hip — LayerNorm, embedding, layout changes and the greedy sampler (logit filters + argmax +
+// log-softmax bookkeeping) for gfx950.  All of these are HBM/L2-bound streaming kernels: 16-byte vector accesses,
+// one wave per row where a row reduction is needed.
+#include "common.h"
+
+namespace wx {
+
+// ---------------------------------------------------------------------------------------------------------
+// LayerNorm (eps 1e-5, affine), fp32 in, fp32 or bf16 out.  One wave per row, two-pass statistics in registers.
+// ---------------------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, TO* __restrict__ out, int rows, int d) {
+    constexpr int MAXV = 8;                       // d <= 64 * 4 * 8 = 2048
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (int64_t)row * d);
+    const int nv = d / 4;
+    f32x4 v[MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        v[i] = (c < nv) ? xr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+        sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    const float mean = sum / (float)d;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float t = v[i][j] - mean; sq = fmaf(t, t, sq); }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off);
+    const float rstd = 1.0f / sqrtf(sq / (float)d + 1e-5f);
+    const f32x4* gr = reinterpret_cast<const f32x4*>(gamma);
+    const f32x4* br = reinterpret_cast<const f32x4*>(beta);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const f32x4 g = gr[c], bb = br[c];
+            f32x4 y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = (v[i][j] - mean) * rstd * g[j] + bb[j];
+            if constexpr (sizeof(TO) == 4) {
+                reinterpret_cast<f32x4*>(out + (int64_t)row * d)[c] = y;
+            } else {
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (bf16)y[j];
+                reinterpret_cast<bf16x4*>(out + (int64_t)row * d)[c] = o;
+            }
+        }
+    }
+}
+
+int launch_layernorm(const float* x, const float* gamma, const float* beta, void* out, int out_dtype, int rows, int d,
+                     hipStream_t st) {
+    if (d % 4 != 0 || d > 2048 || rows <= 0) return -1;
+    const int blocks = (rows + 3) / 4;
+    if (out_dtype == DT_F32) hipLaunchKernelGGL(layernorm_kernel<float>, dim3(blocks), dim3(256), 0, st, x, gamma, beta, (float*)out, rows, d);
+    else hipLaunchKernelGGL(layernorm_kernel<bf16>, dim3(blocks), dim3(256), 0, st, x, gamma, beta, (bf16*)out, rows, d);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// token + positional embedding for the current decode position
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void embed_kernel(const T* __restrict__ tok_emb, const T* __restrict__ pos_emb, const int32_t* __restrict__ tokens,
+                             int ld_tok, const int32_t* __restrict__ d_pos, float* __restrict__ x, int d) {
+    const int b = blockIdx.x, t = *d_pos;
+    const int token = tokens[b * ld_tok + t];
+    const T* te = tok_emb + (int64_t)token * d;
+    const T* pe = pos_emb + (int64_t)t * d;
+    for (int i = threadIdx.x; i < d; i += blockDim.x) x[(int64_t)b * d + i] = (float)te[i] + (float)pe[i];
+}
+
+int launch_embed(const void* tok_emb, const void* pos_emb, int dt, const int32_t* tokens, int ld_tok, const int32_t* d_pos,
+                 float* x, int B, int d, hipStream_t st) {
+    if (dt == DT_F32) hipLaunchKernelGGL(embed_kernel<float>, dim3(B), dim3(256), 0, st, (const float*)tok_emb, (const float*)pos_emb, tokens, ld_tok, d_pos, x, d);
+    else hipLaunchKernelGGL(embed_kernel<bf16>, dim3(B), dim3(256), 0, st, (const bf16*)tok_emb, (const bf16*)pos_emb, tokens, ld_tok, d_pos, x, d);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// dtype conversion
+// ---------------------------------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ void convert_kernel(const TI* __restrict__ in, TO* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (TO)(float)in[i];
+}
+static int grid_for(int64_t n) { int64_t b = (n + 255) / 256; if (b > 8192) b = 8192; if (b < 1) b = 1; return (int)b; }
+
+int launch_convert_f32(const float* in, void* out, int out_dtype, int64_t n, hipStream_t st) {
+    if (out_dtype == DT_F32) hipLaunchKernelGGL((convert_kernel<float, float>), dim3(grid_for(n)), dim3(256), 0, st, in, (float*)out, n);
+    else hipLaunchKernelGGL((convert_kernel<float, bf16>), dim3(grid_for(n)), dim3(256), 0, st, in, (bf16*)out, n);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+int launch_to_f32(const void* in, int in_dtype, float* out, int64_t n, hipStream_t st) {
+    if (in_dtype == DT_F32) hipLaunchKernelGGL((convert_kernel<float, float>), dim3(grid_for(n)), dim3(256), 0, st, (const float*)in, out, n);
+    else hipLaunchKernelGGL((convert_kernel<bf16, float>), dim3(grid_for(n)), dim3(256), 0, st, (const bf16*)in, out, n);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// mel [w][m][t] -> conv input xpad[w][1 + t][c_pad] (time-major, channel-last, one zero row either side)
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void mel_to_conv_kernel(const float* __restrict__ mel, int64_t win_stride, int64_t row_stride,
+                                                          int64_t n_valid_frames, T* __restrict__ xpad, int n_mels, int c_pad) {
+    __shared__ float tile[32][33];
+    const int w = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + i * 8, t = t0 + tx;
+        float v = 0.f;
+        if (c < n_mels && t < WIN_FRAMES && (int64_t)w * WIN_FRAMES + t < n_valid_frames)
+            v = mel[(int64_t)w * win_stride + (int64_t)c * row_stride + t];
+        tile[ty + i * 8][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = t0 + ty + i * 8, c = c0 + tx;
+        if (t < WIN_FRAMES && c < c_pad) xpad[((int64_t)w * (WIN_FRAMES + 2) + 1 + t) * c_pad + c] = (T)tile[tx][ty + i * 8];
+    }
+}
+
+int launch_mel_to_conv_input(const float* mel, int64_t win_stride, int64_t row_stride, int64_t n_valid_frames, void* xpad,
+                             int dt, int B, int n_mels, int c_pad, hipStream_t st) {
+    dim3 grid((WIN_FRAMES + 31) / 32, (c_pad + 31) / 32, B);
+    if (dt == DT_F32) hipLaunchKernelGGL(mel_to_conv_kernel<float>, grid, dim3(256), 0, st, mel, win_stride, row_stride, n_valid_frames, (float*)xpad, n_mels, c_pad);
+    else hipLaunchKernelGGL(mel_to_conv_kernel<bf16>, grid, dim3(256), 0, st, mel, win_stride, row_stride, n_valid_frames, (bf16*)xpad, n_mels, c_pad);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// zero the first and last row of every [rows_per_batch][C] slab
+template <typename T>
+__global__ void zero_pad_rows_kernel(T* __restrict__ x, int rows_per_batch, int C) {
+    const int b = blockIdx.x;
+    T* first = x + (int64_t)b * rows_per_batch * C;
+    T* last = first + (int64_t)(rows_per_batch - 1) * C;
+    for (int i = threadIdx.x; i < C; i += blockDim.x) { first[i] = (T)0.f; last[i] = (T)0.f; }
+}
+int launch_zero_pad_rows(void* xpad, int dt, int B, int rows_per_batch, int C, hipStream_t st) {
+    if (dt == DT_F32) hipLaunchKernelGGL(zero_pad_rows_kernel<float>, dim3(B), dim3(256), 0, st, (float*)xpad, rows_per_batch, C);
+    else hipLaunchKernelGGL(zero_pad_rows_kernel<bf16>, dim3(B), dim3(256), 0, st, (bf16*)xpad, rows_per_batch, C);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Sampler: upstream DecodingTask logit filters + GreedyDecoder.update at temperature 0, one workgroup per sequence.
+//   SuppressBlank (first sampled position), SuppressTokens (byte mask), ApplyTimestampRules (optional),
+//   argmax (lowest index wins ties), log-softmax of the filtered row for sum_logprob, no-speech probability from
+//   the UNfiltered row at the SOT position, EOT stickiness, device-side finished counter, step counter advance.
+// ---------------------------------------------------------------------------------------------------------
+struct MaxIdx { float v; int i; };
+__device__ __forceinline__ MaxIdx better(MaxIdx a, MaxIdx b) {
+    if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
+    return a;
+}
+__device__ __forceinline__ MaxIdx wave_best(MaxIdx x) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        MaxIdx y; y.v = __shfl_xor(x.v, off); y.i = __shfl_xor(x.i, off);
+        x = better(x, y);
+    }
+    return x;
+}
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+    return x;
+}
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x = fmaxf(x, __shfl_xor(x, off));
+    return x;
+}
+
+__global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs s) {
+    __shared__ MaxIdx sh_all[4], sh_ts[4];
+    __shared__ float sh_f[4], sh_g[4];
+    __shared__ int sh_flags[8];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int t = *s.d_pos;
+    const float* lg = s.logits + (int64_t)b * s.ldl;
+    const int V = s.n_vocab;
+
+    if (t == s.sot_index && s.no_speech) {
+        float mx = -INFINITY;
+        for (int i = tid; i < V; i += 256) mx = fmaxf(mx, lg[i]);
+        mx = wave_max(mx);
+        if (lane == 0) sh_f[wid] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(sh_f[0], sh_f[1]), fmaxf(sh_f[2], sh_f[3]));
+        float se = 0.f;
+        for (int i = tid; i < V; i += 256) se += expf(lg[i] - mx);
+        se = wave_sum(se);
+        if (lane == 0) sh_g[wid] = se;
+        __syncthreads();
+        if (tid == 0) s.no_speech[b] = expf(lg[s.tok_no_speech] - mx) / ((sh_g[0] + sh_g[1]) + (sh_g[2] + sh_g[3]));
+        __syncthreads();
+    }
+
+    if (t >= s.n_prompt - 1 && !s.forced) {
+        int32_t* row = s.tokens + (int64_t)b * s.ld_tok;
+        const int tb = s.tok_timestamp_begin;
+        const bool first_step = (t == s.n_prompt - 1);
+        if (tid == 0) {
+            // timestamp-rule ranges (all empty in without_timestamps mode)
+            int a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0, c_hi = 0, d_lo = V;
+            if (!s.without_timestamps) {
+                const int cnt = t - s.n_prompt + 1;                 // sampled tokens so far
+                const bool last_ts = cnt >= 1 && row[t] >= tb;
+                const bool penult_ts = cnt < 2 || row[t - 1] >= tb;
+                if (last_ts) {
+                    if (penult_ts) { a_lo = tb; a_hi = V; } else { a_lo = 0; a_hi = s.tok_eot; }
+                }
+                int ts_last = -1;
+                for (int j = t; j >= s.n_prompt; --j) if (row[j] >= tb) { ts_last = row[j]; break; }
+                if (ts_last >= 0) { b_lo = tb; b_hi = (last_ts && !penult_ts) ? ts_last : ts_last + 1; }
+                if (first_step) {
+                    c_hi = tb;                                      // [0, tb) masked
+                    if (s.max_initial_ts >= 0) d_lo = tb + s.max_initial_ts + 1;   // [d_lo, V) masked
+                }
+            }
+            sh_flags[0] = a_lo; sh_flags[1] = a_hi; sh_flags[2] = b_lo; sh_flags[3] = b_hi; sh_flags[4] = c_hi; sh_flags[5] = d_lo;
+        }
+        __syncthreads();
+        const int a_lo = sh_flags[0], a_hi = sh_flags[1], b_lo = sh_flags[2], b_hi = sh_flags[3], c_hi = sh_flags[4], d_lo = sh_flags[5];
+        const bool ts_mode = !s.without_timestamps;
+        auto masked = [&](int i) -> bool {
+            if (s.suppress[i]) return true;
+            if (first_step && s.suppress_blank && (i == s.tok_blank || i == s.tok_eot)) return true;
+            if (ts_mode) {
+                if (i == s.tok_no_timestamps) return true;
+                if (i >= a_lo && i < a_hi) return true;
+                if (i >= b_lo && i < b_hi) return true;
+                if (i < c_hi || i >= d_lo) return true;
+            }
+            return false;
+        };
+        MaxIdx best_all{-INFINITY, 0x7fffffff}, best_ts{-INFINITY, 0x7fffffff};
+        float max_text = -INFINITY;
+        for (int i = tid; i < V; i += 256) {
+            if (masked(i)) continue;
+            const float v = lg[i];
+            best_all = better(best_all, MaxIdx{v, i});
+            if (i >= tb) best_ts = better(best_ts, MaxIdx{v, i}); else max_text = fmaxf(max_text, v);
+        }
+        best_all = wave_best(best_all); best_ts = wave_best(best_ts); max_text = wave_max(max_text);
+        if (lane == 0) { sh_all[wid] = best_all; sh_ts[wid] = best_ts; sh_f[wid] = max_text; }
+        __syncthreads();
+        best_all = better(better(sh_all[0], sh_all[1]), better(sh_all[2], sh_all[3]));
+        best_ts = better(better(sh_ts[0], sh_ts[1]), better(sh_ts[2], sh_ts[3]));
+        max_text = fmaxf(fmaxf(sh_f[0], sh_f[1]), fmaxf(sh_f[2], sh_f[3]));
+        __syncthreads();
+        float sum_all = 0.f, sum_ts = 0.f;
+        for (int i = tid; i < V; i += 256) {
+            if (masked(i)) continue;
+            const float v = lg[i];
+            sum_all += expf(v - best_all.v);
+            if (i >= tb && ts_mode) sum_ts += expf(v - best_ts.v);
+        }
+        sum_all = wave_sum(sum_all); sum_ts = wave_sum(sum_ts);
+        if (lane == 0) { sh_f[wid] = sum_all; sh_g[wid] = sum_ts; }
+        __syncthreads();
+        if (tid == 0) {
+            sum_all = (sh_f[0] + sh_f[1]) + (sh_f[2] + sh_f[3]);
+            sum_ts = (sh_g[0] + sh_g[1]) + (sh_g[2] + sh_g[3]);
+            int chosen = best_all.i;
+            float logprob = -logf(sum_all);
+            if (ts_mode && best_ts.v > -INFINITY) {
+                const float lse_all = best_all.v + logf(sum_all);
+                const float ts_lp = best_ts.v + logf(sum_ts) - lse_all;
+                const float text_lp = max_text - lse_all;
+                if (ts_lp > text_lp) { chosen = best_ts.i; logprob = -logf(sum_ts); }
+            }
+            const bool alive = row[t] != s.tok_eot;
+            if (alive) s.sum_logprob[b] += logprob;
+            const int next = alive ? chosen : s.tok_eot;
+            row[t + 1] = next;
+            if (alive && next == s.tok_eot) atomicAdd(s.n_finished, 1);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int ticket = atomicAdd(s.d_block_counter, 1);
+        if (ticket == s.B - 1) { *s.d_block_counter = 0; *s.d_pos = t + 1; }
+    }
+}
+
+int launch_sampler(const SamplerArgs& s, hipStream_t st) {
+    if (s.B <= 0 || !s.logits || !s.tokens || !s.d_pos || !s.d_block_counter || !s.suppress) return -1;
+    hipLaunchKernelGGL(sampler_kernel, dim3(s.B), dim3(256), 0, st, s);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// After the loop: count sampled ids before the first EOT and pad the tail of every row with EOT.
+__global__ void finish_tokens_kernel(int32_t* tokens, int ld_tok, int n_prompt, int tok_eot, const int32_t* d_pos, int32_t* n_tokens) {
+    const int b = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    int32_t* row = tokens + (int64_t)b * ld_tok;
+    const int last = *d_pos;             // index of the last written token
+    int n = 0;
+    bool ended = false;
+    for (int j = n_prompt; j < ld_tok; ++j) {
+        if (!ended && j <= last && row[j] != tok_eot) ++n; else { ended = true; row[j] = tok_eot; }
+    }
+    n_tokens[b] = n;
+}
+int launch_finish_tokens(int32_t* tokens, int ld_tok, int n_prompt, int tok_eot, const int32_t* d_pos, int32_t* n_tokens, int B,
+                         hipStream_t st) {
+    hipLaunchKernelGGL(finish_tokens_kernel, dim3(B), dim3(64), 0, st, tokens, ld_tok, n_prompt, tok_eot, d_pos, n_tokens);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // namespace wx

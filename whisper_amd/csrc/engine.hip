@@ -1,0 +1,727 @@
+// engine.hip — engine object + C-ABI (include/whisper_amd.h) for the MI355X local-Whisper path.
+// Owns weights, workspace and KV caches in HBM; orchestrates mel -> encoder -> cross-K/V -> greedy decode as
+// plain kernel launches on the caller's HIP stream, with the decode step captured once into a hipGraph.
+#include "common.h"
+#include "../../include/whisper_amd.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace wx;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) return fail(WX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+#define WX_TRY(expr)                                                                                    \
+    do {                                                                                                \
+        int _r = (expr);                                                                                \
+        if (_r != 0) return fail(_r == -2 ? WX_ERR_HIP : WX_ERR_INVALID, std::string(#expr) + " failed (" + std::to_string(_r) + ")"); \
+    } while (0)
+
+namespace {
+
+struct HostTensor { std::vector<float> data; std::vector<int64_t> shape; };
+
+struct AttnW { void* wqkv = nullptr; float* bqkv = nullptr; void* wo = nullptr; float* bo = nullptr; };
+struct LayerW {
+    float *ln1_g = nullptr, *ln1_b = nullptr;
+    AttnW self;
+    float *lnx_g = nullptr, *lnx_b = nullptr;      // cross-attention LN (decoder only)
+    void* xq = nullptr; float* xbq = nullptr;      // cross query
+    void* xkv = nullptr; float* xbkv = nullptr;    // fused cross key|value
+    void* xo = nullptr; float* xbo = nullptr;
+    float *ln2_g = nullptr, *ln2_b = nullptr;
+    void* w1 = nullptr; float* b1 = nullptr; void* w2 = nullptr; float* b2 = nullptr;
+};
+
+}  // namespace
+
+struct wx_engine {
+    wx_config cfg{};
+    int dt = DT_F32;
+    bool finalized = false;
+    std::map<std::string, HostTensor> staged;
+    std::vector<float> mel_filters_h;
+    std::vector<int32_t> suppress_h;
+    std::vector<void*> allocs;
+    int64_t weight_bytes = 0, work_bytes = 0;
+
+    // dims
+    int d = 0, H = 0, dt_ = 0, Ht = 0, c_pad = 0, vocab_pad = 0, T = 0, n_pages_seq = 0;
+    float qk_scale = 1.f;
+
+    // weights
+    void *conv1_w = nullptr, *conv2_w = nullptr; float *conv1_b = nullptr, *conv2_b = nullptr, *enc_pos = nullptr;
+    std::vector<LayerW> enc, dec;
+    float *lnpost_g = nullptr, *lnpost_b = nullptr, *declnf_g = nullptr, *declnf_b = nullptr;
+    void *tok_emb = nullptr, *dec_pos = nullptr;
+    MelTables mel{};
+    uint8_t* suppress = nullptr;
+
+    // encoder workspace
+    void *xpad1 = nullptr, *xpad2 = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr, *enc_out = nullptr;
+    float* x = nullptr;
+    // decoder state
+    void *crossK = nullptr, *crossV = nullptr, *selfK = nullptr, *selfV = nullptr;
+    int32_t* page_table = nullptr;
+    float* dx = nullptr; void *dxn = nullptr, *dqkv = nullptr, *datt = nullptr, *dhid = nullptr, *dq = nullptr;
+    float* logits = nullptr;
+    int32_t *tokens = nullptr, *d_pos = nullptr, *d_counter = nullptr, *n_finished = nullptr, *n_tokens = nullptr;
+    float *sum_logprob = nullptr, *no_speech = nullptr, *partial = nullptr;
+    int32_t* h_pinned = nullptr;
+    int encoded_B = 0;
+
+    hipStream_t own_stream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    // cached decode-step graph
+    hipGraphExec_t graph_exec = nullptr;
+    std::vector<int> graph_key;
+};
+
+namespace {
+
+int dev_alloc(wx_engine* e, void** p, size_t bytes, bool weight) {
+    if (bytes == 0) bytes = 16;
+    hipError_t r = hipMalloc(p, bytes);
+    if (r != hipSuccess) return fail(WX_ERR_NOMEM, "hipMalloc(" + std::to_string(bytes) + "): " + hipGetErrorString(r));
+    e->allocs.push_back(*p);
+    (weight ? e->weight_bytes : e->work_bytes) += (int64_t)bytes;
+    return 0;
+}
+
+// upload fp32 host data as fp32
+int upload_f32(wx_engine* e, const float* h, size_t n, float** out) {
+    void* p;
+    int r = dev_alloc(e, &p, n * 4, true);
+    if (r) return r;
+    HIP_TRY(hipMemcpy(p, h, n * 4, hipMemcpyHostToDevice));
+    *out = (float*)p;
+    return 0;
+}
+// upload fp32 host data converted to the engine dtype
+int upload_w(wx_engine* e, const float* h, size_t n, void** out) {
+    if (e->dt == DT_F32) return upload_f32(e, h, n, (float**)out);
+    void* tmp;
+    HIP_TRY(hipMalloc(&tmp, n * 4));
+    hipError_t r1 = hipMemcpy(tmp, h, n * 4, hipMemcpyHostToDevice);
+    void* p = nullptr;
+    int r = dev_alloc(e, &p, n * 2, true);
+    if (r == 0 && r1 == hipSuccess) r = launch_convert_f32((const float*)tmp, p, DT_BF16, (int64_t)n, nullptr);
+    hipError_t r2 = hipDeviceSynchronize();
+    (void)hipFree(tmp);
+    if (r1 != hipSuccess || r2 != hipSuccess) return fail(WX_ERR_HIP, "weight upload failed");
+    if (r) return r;
+    *out = p;
+    return 0;
+}
+
+const HostTensor* get(wx_engine* e, const std::string& name, std::initializer_list<int64_t> shape) {
+    auto it = e->staged.find(name);
+    if (it == e->staged.end()) { fail(WX_ERR_STATE, "missing weight tensor " + name); return nullptr; }
+    const HostTensor& t = it->second;
+    if (t.shape != std::vector<int64_t>(shape)) { fail(WX_ERR_INVALID, "wrong shape for " + name); return nullptr; }
+    return &t;
+}
+
+int build_attn(wx_engine* e, const std::string& p, int w, AttnW& out) {
+    const HostTensor *q = get(e, p + ".query.weight", {w, w}), *qb = get(e, p + ".query.bias", {w});
+    const HostTensor *k = get(e, p + ".key.weight", {w, w});
+    const HostTensor *v = get(e, p + ".value.weight", {w, w}), *vb = get(e, p + ".value.bias", {w});
+    const HostTensor *o = get(e, p + ".out.weight", {w, w}), *ob = get(e, p + ".out.bias", {w});
+    if (!q || !qb || !k || !v || !vb || !o || !ob) return WX_ERR_STATE;
+    std::vector<float> fw((size_t)3 * w * w), fb((size_t)3 * w, 0.f);
+    memcpy(fw.data(), q->data.data(), (size_t)w * w * 4);
+    memcpy(fw.data() + (size_t)w * w, k->data.data(), (size_t)w * w * 4);
+    memcpy(fw.data() + (size_t)2 * w * w, v->data.data(), (size_t)w * w * 4);
+    memcpy(fb.data(), qb->data.data(), (size_t)w * 4);
+    memcpy(fb.data() + 2 * w, vb->data.data(), (size_t)w * 4);
+    int r;
+    if ((r = upload_w(e, fw.data(), fw.size(), &out.wqkv))) return r;
+    if ((r = upload_f32(e, fb.data(), fb.size(), &out.bqkv))) return r;
+    if ((r = upload_w(e, o->data.data(), o->data.size(), &out.wo))) return r;
+    if ((r = upload_f32(e, ob->data.data(), ob->data.size(), &out.bo))) return r;
+    return 0;
+}
+
+int build_ln(wx_engine* e, const std::string& p, int w, float** g, float** b) {
+    const HostTensor *gw = get(e, p + ".weight", {w}), *gb = get(e, p + ".bias", {w});
+    if (!gw || !gb) return WX_ERR_STATE;
+    int r;
+    if ((r = upload_f32(e, gw->data.data(), w, g))) return r;
+    return upload_f32(e, gb->data.data(), w, b);
+}
+
+int build_mlp(wx_engine* e, const std::string& p, int w, LayerW& L) {
+    const HostTensor *w1 = get(e, p + ".mlp.0.weight", {4 * w, w}), *b1 = get(e, p + ".mlp.0.bias", {4 * w});
+    const HostTensor *w2 = get(e, p + ".mlp.2.weight", {w, 4 * w}), *b2 = get(e, p + ".mlp.2.bias", {w});
+    if (!w1 || !b1 || !w2 || !b2) return WX_ERR_STATE;
+    int r;
+    if ((r = upload_w(e, w1->data.data(), w1->data.size(), &L.w1))) return r;
+    if ((r = upload_f32(e, b1->data.data(), b1->data.size(), &L.b1))) return r;
+    if ((r = upload_w(e, w2->data.data(), w2->data.size(), &L.w2))) return r;
+    return upload_f32(e, b2->data.data(), b2->data.size(), &L.b2);
+}
+
+// conv weight [out][in][3] -> [out][3][c_pad] (tap-major, channel-last, zero padded channels)
+int build_conv(wx_engine* e, const std::string& p, int out_c, int in_c, int c_pad, void** w, float** b) {
+    const HostTensor *cw = get(e, p + ".weight", {out_c, in_c, 3}), *cb = get(e, p + ".bias", {out_c});
+    if (!cw || !cb) return WX_ERR_STATE;
+    std::vector<float> r((size_t)out_c * 3 * c_pad, 0.f);
+    for (int o = 0; o < out_c; ++o)
+        for (int c = 0; c < in_c; ++c)
+            for (int k = 0; k < 3; ++k) r[((size_t)o * 3 + k) * c_pad + c] = cw->data[((size_t)o * in_c + c) * 3 + k];
+    int rc;
+    if ((rc = upload_w(e, r.data(), r.size(), w))) return rc;
+    return upload_f32(e, cb->data.data(), out_c, b);
+}
+
+GemmArgs gemm_basic(wx_engine* e, const void* A, int64_t lda, const void* W, int M, int N, int K) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.M = M; g.N = N; g.K = K; g.in_dtype = e->dt;
+    return g;
+}
+
+struct StreamScope {   // graph capture needs a real stream: route NULL-stream callers through the engine's own stream
+    wx_engine* e; hipStream_t user, st; bool swapped;
+    StreamScope(wx_engine* e_, void* s) : e(e_), user((hipStream_t)s), st((hipStream_t)s), swapped(false) {
+        if (user == nullptr) {
+            st = e->own_stream; swapped = true;
+            (void)hipEventRecord(e->ev_in, user);
+            (void)hipStreamWaitEvent(st, e->ev_in, 0);
+        }
+    }
+    ~StreamScope() {
+        if (swapped) { (void)hipEventRecord(e->ev_out, st); (void)hipStreamWaitEvent(user, e->ev_out, 0); }
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* wx_last_error(void) { return g_err.c_str(); }
+const char* wx_version(void) { return "whisper_amd 0.1 (gfx950)"; }
+
+int wx_create(const wx_config* cfg, wx_engine** out) {
+    if (!cfg || !out) return fail(WX_ERR_INVALID, "null argument");
+    const wx_config& c = *cfg;
+    if (c.n_audio_state % 128 || c.n_text_state % 128 || c.n_audio_state != c.n_audio_head * HEAD_DIM ||
+        c.n_text_state != c.n_text_head * HEAD_DIM || c.n_audio_state != c.n_text_state)
+        return fail(WX_ERR_INVALID, "state widths must be equal, multiples of 128, with 64-wide heads");
+    if (c.n_audio_ctx != 1500) return fail(WX_ERR_INVALID, "n_audio_ctx must be 1500 (30 s windows)");
+    if (c.n_text_ctx % KV_PAGE || c.n_text_ctx <= 0 || c.n_mels <= 0 || c.n_mels > 256 || c.max_batch <= 0 || c.n_vocab <= 0)
+        return fail(WX_ERR_INVALID, "bad dimensions");
+    if (c.precision != WX_PREC_F32 && c.precision != WX_PREC_BF16) return fail(WX_ERR_INVALID, "bad precision");
+    HIP_TRY(hipSetDevice(c.device));
+    wx_engine* e = new wx_engine();
+    e->cfg = c;
+    e->dt = c.precision == WX_PREC_BF16 ? DT_BF16 : DT_F32;
+    e->d = c.n_audio_state; e->H = c.n_audio_head; e->dt_ = c.n_text_state; e->Ht = c.n_text_head;
+    e->c_pad = (c.n_mels + 63) / 64 * 64;
+    e->vocab_pad = (c.n_vocab + 15) / 16 * 16;
+    e->T = c.n_audio_ctx;
+    e->n_pages_seq = c.n_text_ctx / KV_PAGE;
+    e->qk_scale = powf((float)HEAD_DIM, -0.25f);
+    hipError_t r = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
+    if (r == hipSuccess) r = hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming);
+    if (r == hipSuccess) r = hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming);
+    if (r != hipSuccess) { delete e; return fail(WX_ERR_HIP, hipGetErrorString(r)); }
+    *out = e;
+    return WX_OK;
+}
+
+void wx_destroy(wx_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipDeviceSynchronize();
+    if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
+    for (void* p : e->allocs) (void)hipFree(p);
+    if (e->h_pinned) (void)hipHostFree(e->h_pinned);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    if (e->ev_in) (void)hipEventDestroy(e->ev_in);
+    if (e->ev_out) (void)hipEventDestroy(e->ev_out);
+    delete e;
+}
+
+int wx_set_weight(wx_engine* e, const char* name, const float* h_data, const int64_t* shape, int32_t ndim) {
+    if (!e || !name || !h_data || !shape || ndim <= 0 || ndim > 4) return fail(WX_ERR_INVALID, "bad argument");
+    if (e->finalized) return fail(WX_ERR_STATE, "engine already finalized");
+    HostTensor t;
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) { if (shape[i] <= 0) return fail(WX_ERR_INVALID, "bad shape"); t.shape.push_back(shape[i]); n *= shape[i]; }
+    t.data.assign(h_data, h_data + n);
+    e->staged[name] = std::move(t);
+    return WX_OK;
+}
+
+int wx_set_mel_filters(wx_engine* e, const float* h_filters) {
+    if (!e || !h_filters) return fail(WX_ERR_INVALID, "bad argument");
+    if (e->finalized) return fail(WX_ERR_STATE, "engine already finalized");
+    e->mel_filters_h.assign(h_filters, h_filters + (size_t)e->cfg.n_mels * N_FREQ);
+    return WX_OK;
+}
+
+int wx_set_suppress_tokens(wx_engine* e, const int32_t* h_ids, int32_t n) {
+    if (!e || (n > 0 && !h_ids) || n < 0) return fail(WX_ERR_INVALID, "bad argument");
+    for (int i = 0; i < n; ++i) if (h_ids[i] < 0 || h_ids[i] >= e->cfg.n_vocab) return fail(WX_ERR_INVALID, "suppress id out of range");
+    e->suppress_h.assign(h_ids, h_ids + n);
+    if (e->finalized) {
+        std::vector<uint8_t> m(e->cfg.n_vocab, 0);
+        for (int id : e->suppress_h) m[id] = 1;
+        HIP_TRY(hipMemcpy(e->suppress, m.data(), m.size(), hipMemcpyHostToDevice));
+    }
+    return WX_OK;
+}
+
+int wx_finalize(wx_engine* e) {
+    if (!e) return fail(WX_ERR_INVALID, "null engine");
+    if (e->finalized) return fail(WX_ERR_STATE, "engine already finalized");
+    if (e->mel_filters_h.empty()) return fail(WX_ERR_STATE, "mel filters not set");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const wx_config& c = e->cfg;
+    const int d = e->d, B = c.max_batch, T = e->T;
+    const size_t es = dtype_size(e->dt);
+    int r;
+    // ---- weights ----
+    if ((r = build_conv(e, "encoder.conv1", d, c.n_mels, e->c_pad, &e->conv1_w, &e->conv1_b))) return r;
+    if ((r = build_conv(e, "encoder.conv2", d, d, d, &e->conv2_w, &e->conv2_b))) return r;
+    {
+        const HostTensor* pe = get(e, "encoder.positional_embedding", {T, d});
+        if (!pe) return WX_ERR_STATE;
+        if ((r = upload_f32(e, pe->data.data(), pe->data.size(), &e->enc_pos))) return r;
+    }
+    e->enc.resize(c.n_audio_layer);
+    for (int i = 0; i < c.n_audio_layer; ++i) {
+        const std::string p = "encoder.blocks." + std::to_string(i);
+        LayerW& L = e->enc[i];
+        if ((r = build_ln(e, p + ".attn_ln", d, &L.ln1_g, &L.ln1_b))) return r;
+        if ((r = build_attn(e, p + ".attn", d, L.self))) return r;
+        if ((r = build_ln(e, p + ".mlp_ln", d, &L.ln2_g, &L.ln2_b))) return r;
+        if ((r = build_mlp(e, p, d, L))) return r;
+    }
+    if ((r = build_ln(e, "encoder.ln_post", d, &e->lnpost_g, &e->lnpost_b))) return r;
+    e->dec.resize(c.n_text_layer);
+    for (int i = 0; i < c.n_text_layer; ++i) {
+        const std::string p = "decoder.blocks." + std::to_string(i);
+        LayerW& L = e->dec[i];
+        if ((r = build_ln(e, p + ".attn_ln", d, &L.ln1_g, &L.ln1_b))) return r;
+        if ((r = build_attn(e, p + ".attn", d, L.self))) return r;
+        if ((r = build_ln(e, p + ".cross_attn_ln", d, &L.lnx_g, &L.lnx_b))) return r;
+        {
+            const std::string x = p + ".cross_attn";
+            const HostTensor *q = get(e, x + ".query.weight", {d, d}), *qb = get(e, x + ".query.bias", {d});
+            const HostTensor *k = get(e, x + ".key.weight", {d, d});
+            const HostTensor *v = get(e, x + ".value.weight", {d, d}), *vb = get(e, x + ".value.bias", {d});
+            const HostTensor *o = get(e, x + ".out.weight", {d, d}), *ob = get(e, x + ".out.bias", {d});
+            if (!q || !qb || !k || !v || !vb || !o || !ob) return WX_ERR_STATE;
+            std::vector<float> kv((size_t)2 * d * d), kvb((size_t)2 * d, 0.f);
+            memcpy(kv.data(), k->data.data(), (size_t)d * d * 4);
+            memcpy(kv.data() + (size_t)d * d, v->data.data(), (size_t)d * d * 4);
+            memcpy(kvb.data() + d, vb->data.data(), (size_t)d * 4);
+            if ((r = upload_w(e, q->data.data(), q->data.size(), &L.xq))) return r;
+            if ((r = upload_f32(e, qb->data.data(), d, &L.xbq))) return r;
+            if ((r = upload_w(e, kv.data(), kv.size(), &L.xkv))) return r;
+            if ((r = upload_f32(e, kvb.data(), kvb.size(), &L.xbkv))) return r;
+            if ((r = upload_w(e, o->data.data(), o->data.size(), &L.xo))) return r;
+            if ((r = upload_f32(e, ob->data.data(), d, &L.xbo))) return r;
+        }
+        if ((r = build_ln(e, p + ".mlp_ln", d, &L.ln2_g, &L.ln2_b))) return r;
+        if ((r = build_mlp(e, p, d, L))) return r;
+    }
+    if ((r = build_ln(e, "decoder.ln", d, &e->declnf_g, &e->declnf_b))) return r;
+    {
+        const HostTensor* te = get(e, "decoder.token_embedding.weight", {c.n_vocab, d});
+        const HostTensor* pe = get(e, "decoder.positional_embedding", {c.n_text_ctx, d});
+        if (!te || !pe) return WX_ERR_STATE;
+        std::vector<float> padded((size_t)e->vocab_pad * d, 0.f);
+        memcpy(padded.data(), te->data.data(), te->data.size() * 4);
+        if ((r = upload_w(e, padded.data(), padded.size(), &e->tok_emb))) return r;
+        if ((r = upload_w(e, pe->data.data(), pe->data.size(), &e->dec_pos))) return r;
+    }
+    e->staged.clear();
+    // ---- mel tables ----
+    {
+        std::vector<float> win(N_FFT), cs(N_FFT * 2);
+        for (int i = 0; i < N_FFT; ++i) {
+            win[i] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * i / N_FFT));
+            cs[2 * i] = (float)cos(2.0 * M_PI * i / N_FFT);
+            cs[2 * i + 1] = (float)sin(2.0 * M_PI * i / N_FFT);
+        }
+        std::vector<int32_t> fr(c.n_mels * 2);
+        for (int m = 0; m < c.n_mels; ++m) {
+            int lo = N_FREQ, hi = 0;
+            for (int k = 0; k < N_FREQ; ++k) if (e->mel_filters_h[(size_t)m * N_FREQ + k] != 0.f) { if (k < lo) lo = k; hi = k + 1; }
+            if (lo > hi) lo = hi = 0;
+            fr[2 * m] = lo; fr[2 * m + 1] = hi;
+        }
+        float *w, *t, *f; void* fp;
+        if ((r = upload_f32(e, win.data(), win.size(), &w))) return r;
+        if ((r = upload_f32(e, cs.data(), cs.size(), &t))) return r;
+        if ((r = upload_f32(e, e->mel_filters_h.data(), e->mel_filters_h.size(), &f))) return r;
+        if ((r = dev_alloc(e, &fp, fr.size() * 4, true))) return r;
+        HIP_TRY(hipMemcpy(fp, fr.data(), fr.size() * 4, hipMemcpyHostToDevice));
+        e->mel.window = w; e->mel.cs = t; e->mel.filters = f; e->mel.frange = (const int32_t*)fp; e->mel.n_mels = c.n_mels;
+    }
+    {
+        std::vector<uint8_t> m(c.n_vocab, 0);
+        for (int id : e->suppress_h) m[id] = 1;
+        void* p;
+        if ((r = dev_alloc(e, &p, m.size(), true))) return r;
+        HIP_TRY(hipMemcpy(p, m.data(), m.size(), hipMemcpyHostToDevice));
+        e->suppress = (uint8_t*)p;
+    }
+    // ---- workspace ----
+    const int64_t rows = (int64_t)B * T;
+    auto A = [&](void** p, size_t bytes) { return dev_alloc(e, p, bytes, false); };
+    if ((r = A(&e->xpad1, (size_t)B * (WIN_FRAMES + 2) * e->c_pad * es))) return r;
+    if ((r = A(&e->xpad2, (size_t)B * (WIN_FRAMES + 2) * d * es))) return r;
+    HIP_TRY(hipMemset(e->xpad1, 0, (size_t)B * (WIN_FRAMES + 2) * e->c_pad * es));
+    HIP_TRY(hipMemset(e->xpad2, 0, (size_t)B * (WIN_FRAMES + 2) * d * es));
+    if ((r = A((void**)&e->x, (size_t)rows * d * 4))) return r;
+    if ((r = A(&e->xn, (size_t)rows * d * es))) return r;
+    if ((r = A(&e->qkv, (size_t)3 * rows * d * es))) return r;
+    if ((r = A(&e->att, (size_t)rows * d * es))) return r;
+    if ((r = A(&e->hid, (size_t)rows * 4 * d * es))) return r;
+    if ((r = A(&e->enc_out, (size_t)rows * d * es))) return r;
+    const size_t cross_layer = (size_t)B * e->Ht * T * HEAD_DIM;
+    if ((r = A(&e->crossK, cross_layer * c.n_text_layer * es))) return r;
+    if ((r = A(&e->crossV, cross_layer * c.n_text_layer * es))) return r;
+    const size_t self_layer = (size_t)B * e->n_pages_seq * e->Ht * KV_PAGE * HEAD_DIM;
+    if ((r = A(&e->selfK, self_layer * c.n_text_layer * es))) return r;
+    if ((r = A(&e->selfV, self_layer * c.n_text_layer * es))) return r;
+    if ((r = A((void**)&e->page_table, (size_t)B * e->n_pages_seq * 4))) return r;
+    {
+        std::vector<int32_t> pt((size_t)B * e->n_pages_seq);
+        for (size_t i = 0; i < pt.size(); ++i) pt[i] = (int32_t)i;    // identity allocation: sequence b owns pages b*P .. b*P+P-1
+        HIP_TRY(hipMemcpy(e->page_table, pt.data(), pt.size() * 4, hipMemcpyHostToDevice));
+    }
+    if ((r = A((void**)&e->dx, (size_t)B * d * 4))) return r;
+    if ((r = A(&e->dxn, (size_t)B * d * es))) return r;
+    if ((r = A(&e->dqkv, (size_t)B * 3 * d * es))) return r;
+    if ((r = A(&e->datt, (size_t)B * d * es))) return r;
+    if ((r = A(&e->dhid, (size_t)B * 4 * d * es))) return r;
+    if ((r = A(&e->dq, (size_t)B * d * es))) return r;
+    if ((r = A((void**)&e->logits, (size_t)B * e->vocab_pad * 4))) return r;
+    if ((r = A((void**)&e->tokens, (size_t)B * c.n_text_ctx * 4))) return r;
+    if ((r = A((void**)&e->d_pos, 64))) return r;
+    e->d_counter = e->d_pos + 4; e->n_finished = e->d_pos + 8;
+    HIP_TRY(hipMemset(e->d_pos, 0, 64));
+    if ((r = A((void**)&e->n_tokens, (size_t)B * 4))) return r;
+    if ((r = A((void**)&e->sum_logprob, (size_t)B * 4))) return r;
+    if ((r = A((void**)&e->no_speech, (size_t)B * 4))) return r;
+    if ((r = A((void**)&e->partial, (size_t)B * e->Ht * 8 * (HEAD_DIM + 2) * 4))) return r;
+    HIP_TRY(hipHostMalloc((void**)&e->h_pinned, 64));
+    HIP_TRY(hipDeviceSynchronize());
+    e->finalized = true;
+    return WX_OK;
+}
+
+int wx_mel_reset_max(wx_engine* e, float* d_max, void* stream) {
+    if (!e || !d_max) return fail(WX_ERR_INVALID, "bad argument");
+    WX_TRY(launch_fill_f32(d_max, -INFINITY, 1, (hipStream_t)stream));
+    return WX_OK;
+}
+
+int wx_mel_stage1(wx_engine* e, const float* d_pcm, int64_t pcm_offset, int64_t n_valid, int64_t n_file, int64_t n_total,
+                  int64_t frame0, int64_t n_frames, float* d_logmel, int64_t ld, float* d_max, void* stream) {
+    if (!e || !e->finalized) return fail(WX_ERR_STATE, "engine not finalized");
+    if (!d_pcm || !d_logmel || !d_max || n_frames < 0 || frame0 < 0 || n_file < 0 || n_total < n_file || n_valid < 0 || ld < n_frames)
+        return fail(WX_ERR_INVALID, "bad mel arguments");
+    if (n_total < N_FFT) return fail(WX_ERR_INVALID, "audio shorter than one STFT window");
+    if ((frame0 + n_frames) * HOP > n_total) return fail(WX_ERR_INVALID, "frame range beyond the padded signal");
+    WX_TRY(launch_mel_stage1(e->mel, d_pcm, pcm_offset, n_valid, n_file, n_total, frame0, n_frames, d_logmel, ld, d_max, (hipStream_t)stream));
+    return WX_OK;
+}
+
+int wx_mel_stage2(wx_engine* e, float* d_logmel, int64_t ld, int64_t n_frames, const float* d_max, void* stream) {
+    if (!e || !e->finalized) return fail(WX_ERR_STATE, "engine not finalized");
+    if (!d_logmel || !d_max || n_frames < 0 || ld < n_frames) return fail(WX_ERR_INVALID, "bad mel arguments");
+    WX_TRY(launch_mel_stage2(d_logmel, ld, e->cfg.n_mels, n_frames, d_max, (hipStream_t)stream));
+    return WX_OK;
+}
+
+static int encoder_attention(wx_engine* e, int B, hipStream_t st) {
+    const int d = e->d, T = e->T;
+    const size_t es = dtype_size(e->dt);
+    const int64_t per = (int64_t)B * T * d;    // elements per q/k/v split
+    AttnArgs a;
+    a.dt = e->dt;
+    a.Q = e->qkv; a.q_sb = (int64_t)e->H * T * HEAD_DIM; a.q_sq = HEAD_DIM; a.q_sh = (int64_t)T * HEAD_DIM; a.n_q = T;
+    a.K = (char*)e->qkv + per * es; a.V = (char*)e->qkv + 2 * per * es; a.kv_sbh = (int64_t)T * HEAD_DIM; a.n_keys = T;
+    a.O = e->att; a.o_sb = (int64_t)T * d; a.o_sq = d; a.o_sh = HEAD_DIM;
+    a.B = B; a.H = e->H;
+    if (e->dt == DT_BF16) {
+        int r = launch_attn_flash_bf16(a, st);
+        if (r != -100) return r;       // -100: flash kernel not available, fall through
+    }
+    return launch_attn_rows(a, st);
+}
+
+int wx_encode(wx_engine* e, const float* d_mel, int64_t win_stride, int64_t row_stride, int64_t n_valid_frames, int32_t B,
+              void* stream) {
+    if (!e || !e->finalized) return fail(WX_ERR_STATE, "engine not finalized");
+    if (!d_mel || B <= 0 || B > e->cfg.max_batch || win_stride <= 0 || row_stride <= 0)
+        return fail(WX_ERR_INVALID, "bad encode arguments (B must be 1..max_batch)");
+    hipStream_t st = (hipStream_t)stream;
+    const int d = e->d, T = e->T, dtp = e->dt;
+    const size_t es = dtype_size(dtp);
+    const int M = B * T;
+    WX_TRY(launch_mel_to_conv_input(d_mel, win_stride, row_stride, n_valid_frames, e->xpad1, dtp, B, e->cfg.n_mels, e->c_pad, st));
+    {   // conv1 (k=3, pad 1) + GELU as a GEMM over the padded time-major image
+        GemmArgs g = gemm_basic(e, (char*)e->xpad1 + (size_t)0, e->c_pad, e->conv1_w, B * WIN_FRAMES, d, 3 * e->c_pad);
+        g.a_rows_per_batch = WIN_FRAMES; g.a_batch_stride = (int64_t)(WIN_FRAMES + 2) * e->c_pad;
+        g.ep.bias = e->conv1_b; g.ep.act = 1;
+        g.ep.out = e->xpad2; g.ep.out_dtype = dtp; g.ep.ldo = d;
+        g.ep.out_rows_per_batch = WIN_FRAMES; g.ep.out_batch_rows = WIN_FRAMES + 2; g.ep.out_row_offset = 1;
+        WX_TRY(launch_gemm(g, st));
+    }
+    {   // conv2 (k=3, stride 2, pad 1) + GELU + positional table
+        GemmArgs g = gemm_basic(e, e->xpad2, 2 * d, e->conv2_w, M, d, 3 * d);
+        g.a_rows_per_batch = T; g.a_batch_stride = (int64_t)(WIN_FRAMES + 2) * d;
+        g.ep.bias = e->conv2_b; g.ep.act = 1; g.ep.rowadd = e->enc_pos; g.ep.rowadd_period = T;
+        g.ep.out = e->x; g.ep.out_dtype = DT_F32; g.ep.ldo = d;
+        WX_TRY(launch_gemm(g, st));
+    }
+    const int64_t per = (int64_t)M * d;
+    for (int i = 0; i < e->cfg.n_audio_layer; ++i) {
+        const LayerW& L = e->enc[i];
+        WX_TRY(launch_layernorm(e->x, L.ln1_g, L.ln1_b, e->xn, dtp, M, d, st));
+        {
+            GemmArgs g = gemm_basic(e, e->xn, d, L.self.wqkv, M, 3 * d, d);
+            g.ep.bias = L.self.bqkv; g.ep.colscale_period = d; g.ep.colscale[0] = e->qk_scale; g.ep.colscale[1] = e->qk_scale;
+            g.ep.mode = 1; g.ep.out_dtype = dtp; g.ep.hs_T = T; g.ep.hs_H = e->H; g.ep.hs_d = d;
+            g.ep.out_split[0] = e->qkv; g.ep.out_split[1] = (char*)e->qkv + per * es; g.ep.out_split[2] = (char*)e->qkv + 2 * per * es;
+            WX_TRY(launch_gemm(g, st));
+        }
+        WX_TRY(encoder_attention(e, B, st));
+        {
+            GemmArgs g = gemm_basic(e, e->att, d, L.self.wo, M, d, d);
+            g.ep.bias = L.self.bo; g.ep.residual = e->x; g.ep.ldr = d; g.ep.out = e->x; g.ep.out_dtype = DT_F32; g.ep.ldo = d;
+            WX_TRY(launch_gemm(g, st));
+        }
+        WX_TRY(launch_layernorm(e->x, L.ln2_g, L.ln2_b, e->xn, dtp, M, d, st));
+        {
+            GemmArgs g = gemm_basic(e, e->xn, d, L.w1, M, 4 * d, d);
+            g.ep.bias = L.b1; g.ep.act = 1; g.ep.out = e->hid; g.ep.out_dtype = dtp; g.ep.ldo = 4 * d;
+            WX_TRY(launch_gemm(g, st));
+        }
+        {
+            GemmArgs g = gemm_basic(e, e->hid, 4 * d, L.w2, M, d, 4 * d);
+            g.ep.bias = L.b2; g.ep.residual = e->x; g.ep.ldr = d; g.ep.out = e->x; g.ep.out_dtype = DT_F32; g.ep.ldo = d;
+            WX_TRY(launch_gemm(g, st));
+        }
+    }
+    WX_TRY(launch_layernorm(e->x, e->lnpost_g, e->lnpost_b, e->enc_out, dtp, M, d, st));
+    // cross-attention K/V of every decoder layer, once per window (k pre-scaled by head_dim^-0.25)
+    const size_t cross_layer = (size_t)e->cfg.max_batch * e->Ht * T * HEAD_DIM;
+    for (int i = 0; i < e->cfg.n_text_layer; ++i) {
+        const LayerW& L = e->dec[i];
+        GemmArgs g = gemm_basic(e, e->enc_out, d, L.xkv, M, 2 * d, d);
+        g.ep.bias = L.xbkv; g.ep.colscale_period = d; g.ep.colscale[0] = e->qk_scale;
+        g.ep.mode = 1; g.ep.out_dtype = dtp; g.ep.hs_T = T; g.ep.hs_H = e->Ht; g.ep.hs_d = d;
+        g.ep.out_split[0] = (char*)e->crossK + cross_layer * i * es; g.ep.out_split[1] = (char*)e->crossV + cross_layer * i * es;
+        WX_TRY(launch_gemm(g, st));
+    }
+    e->encoded_B = B;
+    return WX_OK;
+}
+
+int wx_get_encoder_output(wx_engine* e, int32_t B, float* d_out, void* stream) {
+    if (!e || !e->finalized) return fail(WX_ERR_STATE, "engine not finalized");
+    if (!d_out || B <= 0 || B > e->encoded_B) return fail(WX_ERR_INVALID, "no encoder output for that batch");
+    WX_TRY(launch_to_f32(e->enc_out, e->dt, d_out, (int64_t)B * e->T * e->d, (hipStream_t)stream));
+    return WX_OK;
+}
+
+// one decoder step for position *d_pos (all launches read the position from device memory -> graph-replayable)
+static int decode_step(wx_engine* e, int B, const SamplerArgs& sa, hipStream_t st) {
+    const int d = e->d, dtp = e->dt, T = e->T;
+    const size_t es = dtype_size(dtp);
+    const wx_config& c = e->cfg;
+    WX_TRY(launch_embed(e->tok_emb, e->dec_pos, dtp, e->tokens, c.n_text_ctx, e->d_pos, e->dx, B, d, st));
+    const size_t cross_layer = (size_t)c.max_batch * e->Ht * T * HEAD_DIM;
+    const size_t self_layer = (size_t)c.max_batch * e->n_pages_seq * e->Ht * KV_PAGE * HEAD_DIM;
+    int n_split = 1;
+    while (n_split < 6 && B * e->Ht * n_split < 512) ++n_split;
+    for (int i = 0; i < c.n_text_layer; ++i) {
+        const LayerW& L = e->dec[i];
+        WX_TRY(launch_layernorm(e->dx, L.ln1_g, L.ln1_b, e->dxn, dtp, B, d, st));
+        {
+            GemmArgs g = gemm_basic(e, e->dxn, d, L.self.wqkv, B, 3 * d, d);
+            g.ep.bias = L.self.bqkv; g.ep.colscale_period = d; g.ep.colscale[0] = e->qk_scale; g.ep.colscale[1] = e->qk_scale;
+            g.ep.out = e->dqkv; g.ep.out_dtype = dtp; g.ep.ldo = 3 * d;
+            WX_TRY(launch_gemm(g, st));
+        }
+        {
+            AttnArgs a;
+            a.dt = dtp; a.Q = e->dqkv; a.q_sb = 3 * d; a.n_q = 1;
+            a.page_table = e->page_table; a.pt_ld = e->n_pages_seq;
+            a.Kpool = (char*)e->selfK + self_layer * i * es; a.Vpool = (char*)e->selfV + self_layer * i * es;
+            a.Knew = (char*)e->dqkv + (size_t)d * es; a.Vnew = (char*)e->dqkv + (size_t)2 * d * es; a.new_sb = 3 * d;
+            a.d_pos = e->d_pos; a.O = e->datt; a.o_sb = d; a.B = B; a.H = e->Ht; a.n_split = 1;
+            WX_TRY(launch_attn_decode(a, st));
+        }
+        {
+            GemmArgs g = gemm_basic(e, e->datt, d, L.self.wo, B, d, d);
+            g.ep.bias = L.self.bo; g.ep.residual = e->dx; g.ep.ldr = d; g.ep.out = e->dx; g.ep.out_dtype = DT_F32; g.ep.ldo = d;
+            WX_TRY(launch_gemm(g, st));
+        }
+        WX_TRY(launch_layernorm(e->dx, L.lnx_g, L.lnx_b, e->dxn, dtp, B, d, st));
+        {
+            GemmArgs g = gemm_basic(e, e->dxn, d, L.xq, B, d, d);
+            g.ep.bias = L.xbq; g.ep.colscale_period = d; g.ep.colscale[0] = e->qk_scale;
+            g.ep.out = e->dq; g.ep.out_dtype = dtp; g.ep.ldo = d;
+            WX_TRY(launch_gemm(g, st));
+        }
+        {
+            AttnArgs a;
+            a.dt = dtp; a.Q = e->dq; a.q_sb = d; a.n_q = 1;
+            a.K = (char*)e->crossK + cross_layer * i * es; a.V = (char*)e->crossV + cross_layer * i * es;
+            a.kv_sbh = (int64_t)T * HEAD_DIM; a.n_keys = T;
+            a.O = e->datt; a.o_sb = d; a.B = B; a.H = e->Ht; a.n_split = n_split; a.partial = e->partial;
+            WX_TRY(launch_attn_decode(a, st));
+        }
+        {
+            GemmArgs g = gemm_basic(e, e->datt, d, L.xo, B, d, d);
+            g.ep.bias = L.xbo; g.ep.residual = e->dx; g.ep.ldr = d; g.ep.out = e->dx; g.ep.out_dtype = DT_F32; g.ep.ldo = d;
+            WX_TRY(launch_gemm(g, st));
+        }
+        WX_TRY(launch_layernorm(e->dx, L.ln2_g, L.ln2_b, e->dxn, dtp, B, d, st));
+        {
+            GemmArgs g = gemm_basic(e, e->dxn, d, L.w1, B, 4 * d, d);
+            g.ep.bias = L.b1; g.ep.act = 1; g.ep.out = e->dhid; g.ep.out_dtype = dtp; g.ep.ldo = 4 * d;
+            WX_TRY(launch_gemm(g, st));
+        }
+        {
+            GemmArgs g = gemm_basic(e, e->dhid, 4 * d, L.w2, B, d, 4 * d);
+            g.ep.bias = L.b2; g.ep.residual = e->dx; g.ep.ldr = d; g.ep.out = e->dx; g.ep.out_dtype = DT_F32; g.ep.ldo = d;
+            WX_TRY(launch_gemm(g, st));
+        }
+    }
+    WX_TRY(launch_layernorm(e->dx, e->declnf_g, e->declnf_b, e->dxn, dtp, B, d, st));
+    {
+        GemmArgs g = gemm_basic(e, e->dxn, d, e->tok_emb, B, e->vocab_pad, d);
+        g.ep.out = e->logits; g.ep.out_dtype = DT_F32; g.ep.ldo = e->vocab_pad;
+        WX_TRY(launch_gemm(g, st));
+    }
+    WX_TRY(launch_sampler(sa, st));
+    return 0;
+}
+
+static SamplerArgs make_sampler(wx_engine* e, int B, const wx_decode_opts& o, int forced) {
+    const wx_config& c = e->cfg;
+    SamplerArgs s;
+    s.logits = e->logits; s.ldl = e->vocab_pad; s.n_vocab = c.n_vocab;
+    s.tokens = e->tokens; s.ld_tok = c.n_text_ctx; s.d_pos = e->d_pos; s.d_block_counter = e->d_counter;
+    s.suppress = e->suppress; s.sum_logprob = e->sum_logprob; s.no_speech = e->no_speech; s.n_finished = e->n_finished;
+    s.B = B; s.n_prompt = o.n_prompt; s.sot_index = o.sot_index;
+    s.tok_eot = c.tok_eot; s.tok_blank = c.tok_blank; s.tok_no_speech = c.tok_no_speech;
+    s.tok_no_timestamps = c.tok_no_timestamps; s.tok_timestamp_begin = c.tok_timestamp_begin;
+    s.without_timestamps = o.without_timestamps; s.suppress_blank = o.suppress_blank; s.max_initial_ts = o.max_initial_timestamp_index;
+    s.forced = forced;
+    return s;
+}
+
+int wx_decode_greedy(wx_engine* e, int32_t B, const int32_t* h_prompt, const wx_decode_opts* opts, int32_t* d_tokens,
+                     int32_t* d_n_tokens, float* d_sum_logprob, float* d_no_speech_prob, int32_t* h_steps, void* stream) {
+    if (!e || !e->finalized) return fail(WX_ERR_STATE, "engine not finalized");
+    if (!h_prompt || !opts || !d_tokens || !d_n_tokens || !d_sum_logprob || !d_no_speech_prob) return fail(WX_ERR_INVALID, "null argument");
+    if (B <= 0 || B > e->encoded_B) return fail(WX_ERR_INVALID, "decode batch exceeds the last wx_encode batch");
+    const wx_config& c = e->cfg;
+    wx_decode_opts o = *opts;
+    if (o.n_prompt <= 0 || o.n_prompt >= c.n_text_ctx || o.sot_index < 0 || o.sot_index >= o.n_prompt)
+        return fail(WX_ERR_INVALID, "bad prompt length / sot index");
+    for (int i = 0; i < o.n_prompt; ++i) if (h_prompt[i] < 0 || h_prompt[i] >= c.n_vocab) return fail(WX_ERR_INVALID, "prompt id out of range");
+    int sample_len = o.max_new_tokens > 0 ? o.max_new_tokens : c.n_text_ctx / 2;
+    if (o.n_prompt + sample_len > c.n_text_ctx) sample_len = c.n_text_ctx - o.n_prompt;   // upstream stops once len > n_ctx
+    if (o.check_interval < 1) o.check_interval = 8;
+    StreamScope sc(e, stream);
+    hipStream_t st = sc.st;
+    // initial state
+    {
+        std::vector<int32_t> rows((size_t)B * c.n_text_ctx, c.tok_eot);
+        for (int b = 0; b < B; ++b) memcpy(&rows[(size_t)b * c.n_text_ctx], h_prompt, (size_t)o.n_prompt * 4);
+        HIP_TRY(hipMemcpyAsync(e->tokens, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(e->d_pos, 0, 64, st));
+        HIP_TRY(hipMemsetAsync(e->sum_logprob, 0, (size_t)B * 4, st));
+        HIP_TRY(hipMemsetAsync(e->no_speech, 0, (size_t)B * 4, st));
+        HIP_TRY(hipStreamSynchronize(st));   // rows is a stack-lifetime host buffer
+    }
+    const SamplerArgs sa = make_sampler(e, B, o, 0);
+    const int total_steps = o.n_prompt - 1 + sample_len;   // positions 0 .. n_prompt-2 feed the prompt, then sample_len sampling steps
+    hipGraphExec_t exec = nullptr;
+    if (o.use_graph) {
+        std::vector<int> key = {B, o.n_prompt, o.sot_index, o.without_timestamps, o.suppress_blank, o.max_initial_timestamp_index};
+        if (!e->graph_exec || e->graph_key != key) {
+            if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
+            hipGraph_t graph = nullptr;
+            HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+            int r = decode_step(e, B, sa, st);
+            hipError_t ce = hipStreamEndCapture(st, &graph);
+            if (r != 0) { if (graph) (void)hipGraphDestroy(graph); return r; }
+            if (ce != hipSuccess) return fail(WX_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+            hipError_t ie = hipGraphInstantiate(&e->graph_exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ie != hipSuccess) { e->graph_exec = nullptr; return fail(WX_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
+            e->graph_key = key;
+        }
+        exec = e->graph_exec;
+    }
+    int steps_run = 0, sampled = 0;
+    for (int s = 0; s < total_steps; ++s) {
+        if (exec) HIP_TRY(hipGraphLaunch(exec, st));
+        else { int r = decode_step(e, B, sa, st); if (r) return r; }
+        ++steps_run;
+        if (s >= o.n_prompt - 1) {
+            ++sampled;
+            if (sampled % o.check_interval == 0 && s + 1 < total_steps) {
+                HIP_TRY(hipMemcpyAsync(e->h_pinned, e->n_finished, 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                if (e->h_pinned[0] >= B) break;
+            }
+        }
+    }
+    WX_TRY(launch_finish_tokens(e->tokens, c.n_text_ctx, o.n_prompt, c.tok_eot, e->d_pos, e->n_tokens, B, st));
+    HIP_TRY(hipMemcpyAsync(d_tokens, e->tokens, (size_t)B * c.n_text_ctx * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_n_tokens, e->n_tokens, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_sum_logprob, e->sum_logprob, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_no_speech_prob, e->no_speech, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+    if (h_steps) *h_steps = sampled;
+    return WX_OK;
+}
+
+int wx_decoder_logits(wx_engine* e, int32_t B, const int32_t* d_tokens, int32_t n, float* d_logits, void* stream) {
+    if (!e || !e->finalized) return fail(WX_ERR_STATE, "engine not finalized");
+    if (!d_tokens || !d_logits || n <= 0 || n > e->cfg.n_text_ctx) return fail(WX_ERR_INVALID, "bad argument");
+    if (B <= 0 || B > e->encoded_B) return fail(WX_ERR_INVALID, "batch exceeds the last wx_encode batch");
+    const wx_config& c = e->cfg;
+    StreamScope sc(e, stream);
+    hipStream_t st = sc.st;
+    HIP_TRY(hipMemcpy2DAsync(e->tokens, (size_t)c.n_text_ctx * 4, d_tokens, (size_t)n * 4, (size_t)n * 4, B, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemsetAsync(e->d_pos, 0, 64, st));
+    wx_decode_opts o{};
+    o.n_prompt = n; o.sot_index = 0; o.without_timestamps = 1; o.suppress_blank = 0; o.max_initial_timestamp_index = -1;
+    SamplerArgs sa = make_sampler(e, B, o, 1);
+    sa.no_speech = nullptr;
+    for (int t = 0; t < n; ++t) {
+        int r = decode_step(e, B, sa, st);
+        if (r) return r;
+        HIP_TRY(hipMemcpy2DAsync(d_logits + (size_t)t * c.n_vocab, (size_t)n * c.n_vocab * 4, e->logits, (size_t)e->vocab_pad * 4,
+                                 (size_t)c.n_vocab * 4, B, hipMemcpyDeviceToDevice, st));
+    }
+    return WX_OK;
+}
+
+int64_t wx_weight_bytes(wx_engine* e) { return e ? e->weight_bytes : 0; }
+int64_t wx_workspace_bytes(wx_engine* e) { return e ? e->work_bytes : 0; }
+
+}  // extern "C"

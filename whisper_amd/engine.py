@@ -1,0 +1,218 @@
+"""Python host side of the MI355X Whisper engine: owns one ``wx_engine`` handle (C-ABI, include/whisper_amd.h) and
+drives mel -> encoder -> greedy decode for batches of 30 s windows.  PyTorch is used for device buffers and streams
+only; all arithmetic runs in the HIP library.
+
+Replaces what the reference obtains from ``whisper.load_model(...)`` + ``model.transcribe(...)``
+(ref:app/transcription/speech_recognition.py:22,55).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .audio import HOP_LENGTH, N_FRAMES, N_SAMPLES, n_windows, slaney_mel_filterbank
+from .checkpoint import ModelDims, SpecialTokens, non_speech_suppress_ids, special_tokens_for
+
+PRECISIONS = {"fp32": 0, "bf16": 1}
+
+
+def default_suppress_ids(tok: SpecialTokens) -> List[int]:
+    """Upstream ``_get_suppress_tokens`` for ``suppress_tokens="-1"``: non-speech symbols + task/control tokens."""
+    ids = list(non_speech_suppress_ids()) + [tok.transcribe, tok.translate, tok.sot, tok.sot_prev, tok.sot_lm, tok.no_speech]
+    return sorted(set(int(i) for i in ids))
+
+
+def _ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+class WhisperEngine:
+    def __init__(self, dims: ModelDims, state_dict: Dict[str, torch.Tensor], precision: str = "bf16",
+                 max_batch: int = 8, device: int = 0, suppress_ids: Optional[Sequence[int]] = None):
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
+        if not torch.cuda.is_available():
+            raise RuntimeError("whisper_amd needs a ROCm GPU (no CPU fallback)")
+        self.lib = _lib.load()
+        self.dims, self.precision, self.max_batch, self.device = dims, precision, int(max_batch), int(device)
+        self.tok = special_tokens_for(dims.n_vocab)
+        self.torch_device = torch.device("cuda", self.device)
+        t = self.tok
+        cfg = _lib.WxConfig(
+            n_mels=dims.n_mels, n_audio_ctx=dims.n_audio_ctx, n_audio_state=dims.n_audio_state,
+            n_audio_head=dims.n_audio_head, n_audio_layer=dims.n_audio_layer, n_vocab=dims.n_vocab,
+            n_text_ctx=dims.n_text_ctx, n_text_state=dims.n_text_state, n_text_head=dims.n_text_head,
+            n_text_layer=dims.n_text_layer, precision=PRECISIONS[precision], max_batch=self.max_batch, device=self.device,
+            tok_eot=t.eot, tok_sot=t.sot, tok_translate=t.translate, tok_transcribe=t.transcribe, tok_sot_prev=t.sot_prev,
+            tok_sot_lm=t.sot_lm, tok_no_speech=t.no_speech, tok_no_timestamps=t.no_timestamps,
+            tok_timestamp_begin=t.timestamp_begin, tok_blank=t.blank)
+        handle = ctypes.c_void_p()
+        _lib.check(self.lib.wx_create(ctypes.byref(cfg), ctypes.byref(handle)), "wx_create")
+        self.handle = handle
+        try:
+            for name, w in state_dict.items():
+                a = np.ascontiguousarray(w.detach().cpu().float().numpy())
+                shape = (ctypes.c_int64 * a.ndim)(*a.shape)
+                _lib.check(self.lib.wx_set_weight(self.handle, name.encode(), a.ctypes.data_as(ctypes.c_void_p), shape, a.ndim),
+                           f"wx_set_weight({name})")
+            fb = np.ascontiguousarray(slaney_mel_filterbank(dims.n_mels))
+            _lib.check(self.lib.wx_set_mel_filters(self.handle, fb.ctypes.data_as(ctypes.c_void_p)), "wx_set_mel_filters")
+            self.suppress_ids = list(default_suppress_ids(t) if suppress_ids is None else suppress_ids)
+            sup = np.asarray(self.suppress_ids, np.int32)
+            _lib.check(self.lib.wx_set_suppress_tokens(self.handle, sup.ctypes.data_as(ctypes.c_void_p), len(sup)),
+                       "wx_set_suppress_tokens")
+            _lib.check(self.lib.wx_finalize(self.handle), "wx_finalize")
+        except Exception:
+            self.close()
+            raise
+
+    # -- lifetime ---------------------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.wx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self) -> ctypes.c_void_p:
+        return ctypes.c_void_p(torch.cuda.current_stream(self.torch_device).cuda_stream)
+
+    @property
+    def weight_bytes(self) -> int:
+        return int(self.lib.wx_weight_bytes(self.handle))
+
+    @property
+    def workspace_bytes(self) -> int:
+        return int(self.lib.wx_workspace_bytes(self.handle))
+
+    # -- mel ----------------------------------------------------------------------------------------------
+    def mel_stage1(self, pcm: torch.Tensor, pcm_offset: int, n_file: int, n_total: int, frame0: int, n_frames: int,
+                   out: torch.Tensor, gmax: torch.Tensor) -> None:
+        """log10(max(mel, 1e-10)) for file frames [frame0, frame0 + n_frames) into ``out[:, :n_frames]`` and fold the
+        slice maximum into ``gmax`` (1-element fp32 tensor, reset beforehand)."""
+        assert pcm.dtype == torch.float32 and pcm.is_cuda and pcm.is_contiguous() and out.dtype == torch.float32
+        _lib.check(self.lib.wx_mel_stage1(self.handle, _ptr(pcm), pcm_offset, pcm.numel(), n_file, n_total, frame0, n_frames,
+                                          _ptr(out), out.stride(0), _ptr(gmax), self._stream()), "wx_mel_stage1")
+
+    def log_mel(self, pcm: torch.Tensor, padding: int = N_SAMPLES, all_reduce_max=None) -> torch.Tensor:
+        """Whole-buffer log-mel ``[n_mels, (len + padding) // 160]`` (global clamp).  ``all_reduce_max`` is an optional
+        callable applied to the 1-element max tensor between the stages (multi-GPU: all_reduce MAX)."""
+        pcm = pcm.to(self.torch_device, torch.float32).contiguous()
+        n_file = pcm.numel()
+        n_total = n_file + padding
+        n_frames = n_total // HOP_LENGTH
+        out = torch.empty((self.dims.n_mels, n_frames), dtype=torch.float32, device=self.torch_device)
+        gmax = torch.empty(1, dtype=torch.float32, device=self.torch_device)
+        _lib.check(self.lib.wx_mel_reset_max(self.handle, _ptr(gmax), self._stream()), "wx_mel_reset_max")
+        self.mel_stage1(pcm, 0, n_file, n_total, 0, n_frames, out, gmax)
+        if all_reduce_max is not None:
+            all_reduce_max(gmax)
+        self.mel_stage2(out, n_frames, gmax)
+        return out
+
+    def mel_stage2(self, mel: torch.Tensor, n_frames: int, gmax: torch.Tensor) -> None:
+        _lib.check(self.lib.wx_mel_stage2(self.handle, _ptr(mel), mel.stride(0), n_frames, _ptr(gmax), self._stream()),
+                   "wx_mel_stage2")
+
+    def reset_max(self, gmax: torch.Tensor) -> None:
+        _lib.check(self.lib.wx_mel_reset_max(self.handle, _ptr(gmax), self._stream()), "wx_mel_reset_max")
+
+    # -- encoder ------------------------------------------------------------------------------------------
+    def encode(self, mel: torch.Tensor, win_stride: int, row_stride: int, n_valid_frames: int, B: int) -> None:
+        assert mel.dtype == torch.float32 and mel.is_cuda
+        _lib.check(self.lib.wx_encode(self.handle, _ptr(mel), win_stride, row_stride, n_valid_frames, B, self._stream()),
+                   "wx_encode")
+
+    def encode_windows(self, mel_windows: torch.Tensor) -> None:
+        """``mel_windows [B, n_mels, 3000]`` fp32 on device."""
+        mel_windows = mel_windows.to(self.torch_device, torch.float32).contiguous()
+        B = mel_windows.shape[0]
+        assert mel_windows.shape[1:] == (self.dims.n_mels, N_FRAMES)
+        self.encode(mel_windows, self.dims.n_mels * N_FRAMES, N_FRAMES, B * N_FRAMES, B)
+        self._keep = mel_windows
+
+    def encoder_output(self, B: int) -> torch.Tensor:
+        out = torch.empty((B, self.dims.n_audio_ctx, self.dims.n_audio_state), dtype=torch.float32, device=self.torch_device)
+        _lib.check(self.lib.wx_get_encoder_output(self.handle, B, _ptr(out), self._stream()), "wx_get_encoder_output")
+        return out
+
+    # -- decoder ------------------------------------------------------------------------------------------
+    def decode_greedy(self, B: int, prompt: Sequence[int], max_new_tokens: int = 0, without_timestamps: bool = True,
+                      suppress_blank: bool = True, max_initial_timestamp_index: int = 50, use_graph: bool = True,
+                      check_interval: int = 8) -> Dict[str, object]:
+        prompt = [int(p) for p in prompt]
+        opts = _lib.WxDecodeOpts(
+            n_prompt=len(prompt), sot_index=prompt.index(self.tok.sot), max_new_tokens=int(max_new_tokens),
+            without_timestamps=int(without_timestamps), suppress_blank=int(suppress_blank),
+            max_initial_timestamp_index=int(max_initial_timestamp_index), use_graph=int(use_graph),
+            check_interval=int(check_interval))
+        dev = self.torch_device
+        tokens = torch.empty((B, self.dims.n_text_ctx), dtype=torch.int32, device=dev)
+        n_tokens = torch.empty(B, dtype=torch.int32, device=dev)
+        sum_lp = torch.empty(B, dtype=torch.float32, device=dev)
+        nsp = torch.empty(B, dtype=torch.float32, device=dev)
+        steps = ctypes.c_int32(0)
+        h_prompt = (ctypes.c_int32 * len(prompt))(*prompt)
+        _lib.check(self.lib.wx_decode_greedy(self.handle, B, h_prompt, ctypes.byref(opts), _ptr(tokens), _ptr(n_tokens),
+                                             _ptr(sum_lp), _ptr(nsp), ctypes.byref(steps), self._stream()), "wx_decode_greedy")
+        return {"tokens": tokens, "n_tokens": n_tokens, "sum_logprobs": sum_lp, "no_speech_probs": nsp,
+                "steps": int(steps.value), "n_prompt": len(prompt)}
+
+    def decoder_logits(self, tokens: torch.Tensor) -> torch.Tensor:
+        tokens = tokens.to(self.torch_device, torch.int32).contiguous()
+        B, n = tokens.shape
+        out = torch.empty((B, n, self.dims.n_vocab), dtype=torch.float32, device=self.torch_device)
+        _lib.check(self.lib.wx_decoder_logits(self.handle, B, _ptr(tokens), n, _ptr(out), self._stream()), "wx_decoder_logits")
+        return out
+
+    # -- whole path ---------------------------------------------------------------------------------------
+    def initial_tokens(self, language_index: int = 0, task: str = "transcribe", without_timestamps: bool = True,
+                       prompt_ids: Optional[Sequence[int]] = None) -> List[int]:
+        t = self.tok
+        seq = [t.sot, t.lang(language_index), t.transcribe if task == "transcribe" else t.translate]
+        if without_timestamps:
+            seq.append(t.no_timestamps)
+        if prompt_ids:
+            seq = [t.sot_prev] + list(prompt_ids)[-(self.dims.n_text_ctx // 2 - 1):] + seq
+        return seq
+
+    def transcribe_mel(self, mel: torch.Tensor, n_content_frames: int, window_lo: int, window_hi: int,
+                       prompt: Sequence[int], **decode_kw) -> Dict[str, object]:
+        """Decode windows [window_lo, window_hi) of a whole-file mel ``[n_mels, ld]`` in batches of ``max_batch``."""
+        toks: List[List[int]] = []
+        sums: List[float] = []
+        nsp: List[float] = []
+        steps = 0
+        ld = mel.stride(0)
+        for w0 in range(window_lo, window_hi, self.max_batch):
+            B = min(self.max_batch, window_hi - w0)
+            view = mel[:, w0 * N_FRAMES:]
+            self.encode(view, N_FRAMES, ld, n_content_frames - w0 * N_FRAMES, B)
+            r = self.decode_greedy(B, prompt, **decode_kw)
+            t_cpu, n_cpu = r["tokens"].cpu(), r["n_tokens"].cpu()
+            for b in range(B):
+                toks.append(t_cpu[b, r["n_prompt"]:r["n_prompt"] + int(n_cpu[b])].tolist())
+            sums += r["sum_logprobs"].cpu().tolist()
+            nsp += r["no_speech_probs"].cpu().tolist()
+            steps += r["steps"]
+        return {"tokens": toks, "sum_logprobs": sums, "no_speech_probs": nsp, "steps": steps}
+
+    def transcribe_pcm(self, audio, prompt: Sequence[int], **decode_kw) -> Dict[str, object]:
+        """Single-process long-form path: whole-file log-mel (+30 s zero padding, global clamp), independent 30 s
+        windows, greedy decode.  ``audio``: float32 mono 16 kHz array or tensor."""
+        pcm = torch.as_tensor(np.asarray(audio, dtype=np.float32) if not torch.is_tensor(audio) else audio)
+        pcm = pcm.to(self.torch_device, torch.float32).contiguous()
+        mel = self.log_mel(pcm)
+        content = pcm.numel() // HOP_LENGTH
+        nw = n_windows(pcm.numel())
+        out = self.transcribe_mel(mel, content, 0, nw, prompt, **decode_kw)
+        out["n_windows"] = nw
+        return out
