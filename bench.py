@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py — RTFx (audio-seconds per wall-second) of the local Whisper path on MI355X.
+
+One "step" = one full pass of the hot path over one batch of synthetic 30 s windows that is already resident in
+HBM: log-mel (whole-buffer clamp) -> encoder -> cross-K/V projection -> greedy decode to EOT or upstream's
+sample_len (224 new tokens).  N=1 workload = BASELINE.json configs[2]: Whisper large-v3, bf16, greedy, batch 64
+windows on one MI355X.  With N>1 every rank runs the same per-GPU workload on its own windows of one long virtual
+file (weak scaling); the only collectives are the 4-byte MAX all-reduce of the mel clamp and the final all-gather of
+token ids.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     — the dominant kernel (decoder cross-attention, HBM-bound): algorithmic bytes per launch divided by
+                 its mean launch duration measured with HIP events on the launch stream in an eager, event-bracketed
+                 decode pass over the same batch (the timed region itself replays a hipGraph per step, which events
+                 cannot look inside; profiles/ holds the rocprofv3 kernel stats of the same command for comparison);
+  cpu_baseline — the CPU oracle (oracle/whisper_oracle.py, PyTorch fp32) timed on the host cores on one window.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from whisper_amd import checkpoint as ck                      # noqa: E402
+from whisper_amd.audio import N_FRAMES, N_SAMPLES, synthetic_audio  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy ceiling)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--model", default="large-v3")
+    p.add_argument("--batch", type=int, default=64, help="30 s windows per GPU per step")
+    p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--max-new-tokens", type=int, default=0, help="0 = upstream sample_len (n_text_ctx // 2)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--cpu-decode-steps", type=int, default=24)
+    return p.parse_args()
+
+
+def cpu_baseline(dims, sd, tok, suppress_ids, gpu_steps_per_window: int, decode_steps: int):
+    """Oracle (kind 'port') on the host cores: one window of the same workload; decode timed over `decode_steps`
+    steps and extrapolated linearly to the GPU run's step count (decode cost per step is constant up to the small
+    self-attention term)."""
+    from oracle import whisper_oracle as wo
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    om = wo.OracleWhisper(dims, sd)
+    audio = synthetic_audio(0)
+    init = wo.initial_tokens(tok, 0)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        mel = wo.log_mel_spectrogram(audio, dims.n_mels, padding=wo.N_SAMPLES)[:, :wo.N_FRAMES]
+        t1 = time.perf_counter()
+        xa = om.encode(mel[None])
+        t2 = time.perf_counter()
+        r = wo.greedy_decode(om, xa, init, tok, suppress_ids, max_new_tokens=decode_steps)
+        t3 = time.perf_counter()
+    per_step = (t3 - t2) / max(1, r["steps"])
+    total = (t1 - t0) + (t2 - t1) + per_step * gpu_steps_per_window
+    return {
+        "value": 30.0 / total, "unit": "audio-sec/sec", "cores": cores, "kind": "port",
+        "sample": (f"oracle/whisper_oracle.py (PyTorch fp32) on 1 window of the same workload: mel {t1 - t0:.2f}s, encoder "
+                   f"{t2 - t1:.2f}s, {r['steps']} greedy steps {t3 - t2:.2f}s, decode extrapolated linearly to "
+                   f"{gpu_steps_per_window} steps; weight load excluded"),
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from whisper_amd.dist import sharded_mel
+    from whisper_amd.engine import WhisperEngine
+
+    dims = ck.dims_for(args.model)
+    tok = ck.special_tokens_for(dims.n_vocab)
+    B = args.batch
+    sd = ck.synthetic_state_dict(dims, seed=0)
+    eng = WhisperEngine(dims, sd, precision=args.precision, max_batch=B, device=local_rank)
+    prompt = eng.initial_tokens(0)
+
+    # this rank's windows of one long virtual file of world*B windows; clip i of the file uses seed i
+    w_lo, w_hi = rank * B, (rank + 1) * B
+    n_file = world * B * N_SAMPLES
+    host = np.concatenate([synthetic_audio(w) for w in range(w_lo, w_hi)])
+    s_lo = w_lo * N_SAMPLES
+    pcm = torch.from_numpy(host).to(dev)          # resident in HBM before the timed region
+    del host
+
+    stream = torch.cuda.Stream(device=dev)
+    state = {}
+
+    def step(use_graph=True, profile_stride=0):
+        mel = sharded_mel(eng, pcm, s_lo, n_file, w_lo, w_hi)
+        eng.encode(mel, N_FRAMES, mel.stride(0), n_file // 160 - w_lo * N_FRAMES, B)
+        r = eng.decode_greedy(B, prompt, max_new_tokens=args.max_new_tokens, use_graph=use_graph,
+                              profile_stride=profile_stride)
+        if world > 1:      # result gather: padded ids + lengths, ~115 KB per rank
+            out = [torch.empty_like(r["tokens"]) for _ in range(world)]
+            dist.all_gather(out, r["tokens"])
+            lens = [torch.empty_like(r["n_tokens"]) for _ in range(world)]
+            dist.all_gather(lens, r["n_tokens"])
+        state["r"], state["mel"] = r, mel
+        return r
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            step(not args.no_graph)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            r = step(not args.no_graph)
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        steps_per_window = int(r["steps"])
+        n_tokens = r["n_tokens"].float().mean().item()
+
+        # dominant kernel: event-bracketed eager pass on the same batch
+        step(use_graph=False, profile_stride=8)
+        torch.cuda.synchronize(dev)
+        prof_ms, prof_n = eng.last_profile()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        es = 2 if args.precision == "bf16" else 4
+        audio_sec = world * B * 30.0 * args.steps
+        value = audio_sec / elapsed
+        bytes_per_launch = B * dims.n_text_head * 2 * dims.n_audio_ctx * 64 * es      # K and V of every (b, h), read once
+        avg_ms = prof_ms / max(1, prof_n)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if prof_n else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "cross_attn_pmc.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "audio-sec/sec (RTFx) whole node, large-v3 greedy, 1/2/4/8 MI355X",
+            "value": value, "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {
+                "workload": f"Whisper {args.model} {args.precision} greedy, batch {B} x 30 s windows per GPU: log-mel + encoder + "
+                            f"cross-K/V + KV-cache decode (BASELINE.json configs[2])",
+                "windows_per_gpu": B, "decode_steps_per_window": steps_per_window, "mean_new_tokens": n_tokens,
+                "prompt": "[sot, <|en|>, transcribe, notimestamps]", "weights": "seeded random init (no checkpoints offline)",
+                "hip_graph": not args.no_graph, "parallelism": f"window-dp{world}",
+            },
+            "roofline": {
+                "kernel": "attn_decode_kernel<bf16,false> (decoder cross-attention)" if es == 2 else "attn_decode_kernel<float,false>",
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms, "launches_timed": prof_n,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(dims, sd, tok, eng.suppress_ids, steps_per_window, args.cpu_decode_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -57,6 +57,8 @@ typedef struct {
     int32_t max_initial_timestamp_index; /* upstream default 50 (1.0 s / 0.02 s); < 0 disables */
     int32_t use_graph;           /* 1: replay one captured hipGraph per decode step; 0: eager launches */
     int32_t check_interval;      /* host polls the device-side finished counter every this many steps (>=1) */
+    int32_t profile_stride;      /* > 0 (eager mode only): bracket every cross-attention launch of every
+                                    profile_stride-th sampling step with HIP events on the launch stream */
 } wx_decode_opts;
 
 const char* wx_last_error(void);
@@ -106,7 +108,10 @@ int wx_decode_greedy(wx_engine* e, int32_t B, const int32_t* h_prompt, const wx_
  * last wx_encode, written to d_logits [B][n][n_vocab] fp32.  Parity/debug entry point. */
 int wx_decoder_logits(wx_engine* e, int32_t B, const int32_t* d_tokens, int32_t n, float* d_logits, void* stream);
 
-/* introspection for benchmarks: name/launch-count of the dominant kernel and algorithmic byte counts */
+/* result of the last profiled wx_decode_greedy: summed HIP-event time of the bracketed cross-attention launches */
+int wx_get_profile(wx_engine* e, double* total_ms, int64_t* launches);
+
+/* introspection for benchmarks */
 int64_t wx_weight_bytes(wx_engine* e);
 int64_t wx_workspace_bytes(wx_engine* e);
 

@@ -23,7 +23,7 @@ class WxConfig(ctypes.Structure):
 class WxDecodeOpts(ctypes.Structure):
     _fields_ = [(n, c_i32) for n in (
         "n_prompt", "sot_index", "max_new_tokens", "without_timestamps", "suppress_blank",
-        "max_initial_timestamp_index", "use_graph", "check_interval")]
+        "max_initial_timestamp_index", "use_graph", "check_interval", "profile_stride")]
 
 
 # name -> (restype, argtypes); exactly the declarations of include/whisper_amd.h
@@ -43,6 +43,7 @@ PROTOTYPES = {
     "wx_get_encoder_output": (c_i32, [c_vp, c_i32, c_vp, c_vp]),
     "wx_decode_greedy": (c_i32, [c_vp, c_i32, c_vp, ctypes.POINTER(WxDecodeOpts), c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_i32), c_vp]),
     "wx_decoder_logits": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp]),
+    "wx_get_profile": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
     "wx_weight_bytes": (c_i64, [c_vp]),
     "wx_workspace_bytes": (c_i64, [c_vp]),
 }

@@ -85,6 +85,12 @@ struct wx_engine {
     // cached decode-step graph
     hipGraphExec_t graph_exec = nullptr;
     std::vector<int> graph_key;
+    // optional event brackets around cross-attention launches (eager mode)
+    std::vector<hipEvent_t> prof_events;
+    size_t prof_used = 0;
+    bool prof_on = false;
+    double prof_ms = 0.0;
+    int64_t prof_launches = 0;
 };
 
 namespace {
@@ -244,6 +250,7 @@ void wx_destroy(wx_engine* e) {
     (void)hipSetDevice(e->cfg.device);
     (void)hipDeviceSynchronize();
     if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
+    for (hipEvent_t ev : e->prof_events) (void)hipEventDestroy(ev);
     for (void* p : e->allocs) (void)hipFree(p);
     if (e->h_pinned) (void)hipHostFree(e->h_pinned);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -588,7 +595,10 @@ static int decode_step(wx_engine* e, int B, const SamplerArgs& sa, hipStream_t s
             a.K = (char*)e->crossK + cross_layer * i * es; a.V = (char*)e->crossV + cross_layer * i * es;
             a.kv_sbh = (int64_t)T * HEAD_DIM; a.n_keys = T;
             a.O = e->datt; a.o_sb = d; a.B = B; a.H = e->Ht; a.n_split = n_split; a.partial = e->partial;
+            const bool prof = e->prof_on && e->prof_used + 2 <= e->prof_events.size();
+            if (prof) HIP_TRY(hipEventRecord(e->prof_events[e->prof_used], st));
             WX_TRY(launch_attn_decode(a, st));
+            if (prof) { HIP_TRY(hipEventRecord(e->prof_events[e->prof_used + 1], st)); e->prof_used += 2; }
         }
         {
             GemmArgs g = gemm_basic(e, e->datt, d, L.xo, B, d, d);
@@ -676,11 +686,17 @@ int wx_decode_greedy(wx_engine* e, int32_t B, const int32_t* h_prompt, const wx_
         }
         exec = e->graph_exec;
     }
-    int steps_run = 0, sampled = 0;
+    int sampled = 0;
+    const bool want_prof = !exec && o.profile_stride > 0;
+    if (want_prof && e->prof_events.empty()) {
+        e->prof_events.resize((size_t)2 * c.n_text_layer * 32);
+        for (auto& ev : e->prof_events) HIP_TRY(hipEventCreate(&ev));
+    }
+    e->prof_used = 0; e->prof_ms = 0.0; e->prof_launches = 0;
     for (int s = 0; s < total_steps; ++s) {
+        e->prof_on = want_prof && s >= o.n_prompt - 1 && ((s - (o.n_prompt - 1)) % o.profile_stride == 0);
         if (exec) HIP_TRY(hipGraphLaunch(exec, st));
-        else { int r = decode_step(e, B, sa, st); if (r) return r; }
-        ++steps_run;
+        else { int r = decode_step(e, B, sa, st); e->prof_on = false; if (r) return r; }
         if (s >= o.n_prompt - 1) {
             ++sampled;
             if (sampled % o.check_interval == 0 && s + 1 < total_steps) {
@@ -696,6 +712,20 @@ int wx_decode_greedy(wx_engine* e, int32_t B, const int32_t* h_prompt, const wx_
     HIP_TRY(hipMemcpyAsync(d_sum_logprob, e->sum_logprob, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_no_speech_prob, e->no_speech, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
     if (h_steps) *h_steps = sampled;
+    if (want_prof) {
+        HIP_TRY(hipStreamSynchronize(st));
+        for (size_t i = 0; i + 1 < e->prof_used; i += 2) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, e->prof_events[i], e->prof_events[i + 1]));
+            e->prof_ms += ms; ++e->prof_launches;
+        }
+    }
+    return WX_OK;
+}
+
+int wx_get_profile(wx_engine* e, double* total_ms, int64_t* launches) {
+    if (!e || !total_ms || !launches) return fail(WX_ERR_INVALID, "null argument");
+    *total_ms = e->prof_ms; *launches = e->prof_launches;
     return WX_OK;
 }
 

@@ -147,13 +147,13 @@ class WhisperEngine:
     # -- decoder ------------------------------------------------------------------------------------------
     def decode_greedy(self, B: int, prompt: Sequence[int], max_new_tokens: int = 0, without_timestamps: bool = True,
                       suppress_blank: bool = True, max_initial_timestamp_index: int = 50, use_graph: bool = True,
-                      check_interval: int = 8) -> Dict[str, object]:
+                      check_interval: int = 8, profile_stride: int = 0) -> Dict[str, object]:
         prompt = [int(p) for p in prompt]
         opts = _lib.WxDecodeOpts(
             n_prompt=len(prompt), sot_index=prompt.index(self.tok.sot), max_new_tokens=int(max_new_tokens),
             without_timestamps=int(without_timestamps), suppress_blank=int(suppress_blank),
             max_initial_timestamp_index=int(max_initial_timestamp_index), use_graph=int(use_graph),
-            check_interval=int(check_interval))
+            check_interval=int(check_interval), profile_stride=int(profile_stride))
         dev = self.torch_device
         tokens = torch.empty((B, self.dims.n_text_ctx), dtype=torch.int32, device=dev)
         n_tokens = torch.empty(B, dtype=torch.int32, device=dev)
@@ -165,6 +165,12 @@ class WhisperEngine:
                                              _ptr(sum_lp), _ptr(nsp), ctypes.byref(steps), self._stream()), "wx_decode_greedy")
         return {"tokens": tokens, "n_tokens": n_tokens, "sum_logprobs": sum_lp, "no_speech_probs": nsp,
                 "steps": int(steps.value), "n_prompt": len(prompt)}
+
+    def last_profile(self):
+        """(total_ms, launches) of the cross-attention launches bracketed by the last profiled eager decode."""
+        ms, n = ctypes.c_double(0.0), ctypes.c_int64(0)
+        _lib.check(self.lib.wx_get_profile(self.handle, ctypes.byref(ms), ctypes.byref(n)), "wx_get_profile")
+        return float(ms.value), int(n.value)
 
     def decoder_logits(self, tokens: torch.Tensor) -> torch.Tensor:
         tokens = tokens.to(self.torch_device, torch.int32).contiguous()
