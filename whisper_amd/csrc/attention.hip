@@ -353,8 +353,4 @@ int launch_attn_rows(const AttnArgs& a, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-#ifndef WX_HAVE_FLASH
-int launch_attn_flash_bf16(const AttnArgs&, hipStream_t) { return -100; }   // -100 = not built; caller falls back to attn_rows
-#endif
-
 }  // namespace wx

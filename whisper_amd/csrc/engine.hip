@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -466,10 +467,9 @@ static int encoder_attention(wx_engine* e, int B, hipStream_t st) {
     a.K = (char*)e->qkv + per * es; a.V = (char*)e->qkv + 2 * per * es; a.kv_sbh = (int64_t)T * HEAD_DIM; a.n_keys = T;
     a.O = e->att; a.o_sb = (int64_t)T * d; a.o_sq = d; a.o_sh = HEAD_DIM;
     a.B = B; a.H = e->H;
-    if (e->dt == DT_BF16) {
-        int r = launch_attn_flash_bf16(a, st);
-        if (r != -100) return r;       // -100: flash kernel not available, fall through
-    }
+    // WX_NO_FLASH=1 routes bf16 through the streaming kernel too (A/B checks of the MFMA kernel)
+    static const bool no_flash = getenv("WX_NO_FLASH") != nullptr;
+    if (e->dt == DT_BF16 && !no_flash) return launch_attn_flash_bf16(a, st);
     return launch_attn_rows(a, st);
 }
 

@@ -156,13 +156,39 @@ __global__ __launch_bounds__(256) void gemm_bf16_tile_kernel(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// bf16 skinny (M <= 64): wave per 16 output columns, weights streamed to registers
+// bf16 skinny (M <= 64): decode-time weight streaming.
+// One workgroup owns 16 output columns; its 4 waves split K four ways (in-workgroup split-K, reduced through LDS in a
+// fixed order, so results are deterministic).  Weight rows and activation fragments go straight from global memory
+// to VGPRs as MFMA operands; loads are software-pipelined two groups (4 k-steps of 32) deep so ~20 KB per wave are
+// in flight while the previous group's MFMAs issue.
 // ---------------------------------------------------------------------------------------------------------
 template <int MT>
-__global__ __launch_bounds__(256) void gemm_bf16_skinny_kernel(GemmArgs g) {
+struct SkinnyFrag { bf16x8 w[2]; bf16x8 x[MT][2]; };
+
+template <int MT>
+__device__ __forceinline__ void skinny_load(SkinnyFrag<MT>& f, const bf16* wp, const bf16* const (&xp)[MT], int k) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) f.w[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + k + u * 32));
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) f.x[i][u] = *reinterpret_cast<const bf16x8*>(xp[i] + k + u * 32);
+}
+template <int MT>
+__device__ __forceinline__ void skinny_mma(const SkinnyFrag<MT>& f, f32x4 (&acc)[MT]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[u], f.x[i][u], acc[i], 0, 0, 0);
+}
+
+constexpr int SK_WAVES = 8;     // waves per workgroup = in-workgroup K split
+
+template <int MT>
+__global__ __launch_bounds__(64 * SK_WAVES) void gemm_bf16_skinny_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float red[SK_WAVES][MT][4][64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int n0 = (blockIdx.x * 4 + wid) * 16;
-    if (n0 >= g.N) return;
+    const int n0 = blockIdx.x * 16;
     const int gq = lane >> 4, r = lane & 15;
     const bf16* A = reinterpret_cast<const bf16*>(g.A);
     int n = n0 + r; if (n > g.N - 1) n = g.N - 1;
@@ -176,31 +202,44 @@ __global__ __launch_bounds__(256) void gemm_bf16_skinny_kernel(GemmArgs g) {
     f32x4 acc[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int U = 4;
-    int k0 = 0;
-    for (; k0 + 32 * U <= g.K; k0 += 32 * U) {
-        bf16x8 w[U], x[MT][U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + k0 + u * 32));
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int u = 0; u < U; ++u) x[i][u] = *reinterpret_cast<const bf16x8*>(xp[i] + k0 + u * 32);
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[u], x[i][u], acc[i], 0, 0, 0);
+    const int ngroups = g.K / 64;                       // launch_gemm guarantees K % 64 == 0
+    const int per = (ngroups + SK_WAVES - 1) / SK_WAVES;
+    const int wu = __builtin_amdgcn_readfirstlane(wid); // provably wave-uniform: scalar loop control
+    const int g0 = wu * per;                            // contiguous K slice per wave: full 128-B lines per row
+    int g1 = g0 + per; if (g1 > ngroups) g1 = ngroups;
+    // Batches of three 64-wide K groups: 30 loads (15 KB per wave) issued back to back, then their MFMAs behind
+    // counted waits.  Loads past the slice are clamped to a valid address and their result is not used, so no load
+    // sits under a branch (a conditional load makes hipcc drain vmcnt(0) per element).
+    for (int gi = g0; gi < g1; gi += 3) {
+        SkinnyFrag<MT> fa, fb, fc;
+        const int ga = gi, gb = gi + 1 < ngroups ? gi + 1 : ngroups - 1, gc = gi + 2 < ngroups ? gi + 2 : ngroups - 1;
+        skinny_load<MT>(fa, wp, xp, ga * 64);
+        skinny_load<MT>(fb, wp, xp, gb * 64);
+        skinny_load<MT>(fc, wp, xp, gc * 64);
+        skinny_mma<MT>(fa, acc);
+        if (gi + 1 < g1) skinny_mma<MT>(fb, acc);
+        if (gi + 2 < g1) skinny_mma<MT>(fc, acc);
     }
-    for (; k0 < g.K; k0 += 32) {
-        const bf16x8 w = *reinterpret_cast<const bf16x8*>(wp + k0);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const bf16x8 x = *reinterpret_cast<const bf16x8*>(xp[i] + k0);
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, acc[i], 0, 0, 0);
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[wid][i][j][lane] = acc[i][j];
+    __syncthreads();
+    // wave w < MT finalises row tile w (fixed summation order over the K slices -> deterministic)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        if (i == wid) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = red[0][i][j][lane];
+#pragma unroll
+                for (int w = 1; w < SK_WAVES; ++w) t += red[w][i][j][lane];
+                v[j] = t;
+            }
+            epilogue_store4(g.ep, i * 16 + r, n0 + gq * 4, v, g.M, g.N);
         }
     }
-#pragma unroll
-    for (int i = 0; i < MT; ++i) epilogue_store4(g.ep, i * 16 + r, n0 + gq * 4, acc[i], g.M, g.N);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -292,14 +331,14 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
     if (g.ep.colscale_period && (g.ep.colscale_period % 4 != 0 || (g.N + g.ep.colscale_period - 1) / g.ep.colscale_period > 3)) return -1;
     if (g.in_dtype == DT_BF16) {
         if (g.M <= 64) {
-            if (g.K % 32 != 0) return -1;
-            const int waves = (g.N + 15) / 16, blocks = (waves + 3) / 4;
+            if (g.K % 64 != 0) return -1;
+            const int blocks = (g.N + 15) / 16;
             const int mt = (g.M + 15) / 16;
             switch (mt) {
-                case 1: hipLaunchKernelGGL(gemm_bf16_skinny_kernel<1>, dim3(blocks), dim3(256), 0, st, g); break;
-                case 2: hipLaunchKernelGGL(gemm_bf16_skinny_kernel<2>, dim3(blocks), dim3(256), 0, st, g); break;
-                case 3: hipLaunchKernelGGL(gemm_bf16_skinny_kernel<3>, dim3(blocks), dim3(256), 0, st, g); break;
-                default: hipLaunchKernelGGL(gemm_bf16_skinny_kernel<4>, dim3(blocks), dim3(256), 0, st, g); break;
+                case 1: hipLaunchKernelGGL(gemm_bf16_skinny_kernel<1>, dim3(blocks), dim3(64 * SK_WAVES), 0, st, g); break;
+                case 2: hipLaunchKernelGGL(gemm_bf16_skinny_kernel<2>, dim3(blocks), dim3(64 * SK_WAVES), 0, st, g); break;
+                case 3: hipLaunchKernelGGL(gemm_bf16_skinny_kernel<3>, dim3(blocks), dim3(64 * SK_WAVES), 0, st, g); break;
+                default: hipLaunchKernelGGL(gemm_bf16_skinny_kernel<4>, dim3(blocks), dim3(64 * SK_WAVES), 0, st, g); break;
             }
         } else {
             if (g.K % TB_BK != 0) return -1;
