@@ -216,6 +216,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_bf16_skinny_kernel(GemmArg
         skinny_load<MT>(fa, wp, xp, ga * 64);
         skinny_load<MT>(fb, wp, xp, gb * 64);
         skinny_load<MT>(fc, wp, xp, gc * 64);
+        __builtin_amdgcn_sched_barrier(0);   // keep all 30 loads in flight: hipcc otherwise sinks loads next to their MFMAs
         skinny_mma<MT>(fa, acc);
         if (gi + 1 < g1) skinny_mma<MT>(fb, acc);
         if (gi + 2 < g1) skinny_mma<MT>(fc, acc);
