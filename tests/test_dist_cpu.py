@@ -1,0 +1,105 @@
+"""N>1 path on CPU: world_size-2 gloo run of whisper_amd.dist.transcribe_sharded with a CPU stand-in engine built on the
+oracle (tests only).  Checks the window partition, the PCM halo, the MAX all-reduce of the mel clamp and the token
+all-gather against the single-process oracle result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import whisper_oracle as wo
+from whisper_amd import checkpoint as ck
+from whisper_amd import dist as wdist
+from whisper_amd.audio import N_FRAMES
+
+
+class OracleEngine:
+    """Duck-typed stand-in for WhisperEngine (mel_stage1/2, reset_max, transcribe_mel) on the CPU oracle."""
+
+    def __init__(self, dims, sd, max_new):
+        self.dims, self.tok = dims, ck.special_tokens_for(dims.n_vocab)
+        self.torch_device = torch.device("cpu")
+        self.om = wo.OracleWhisper(dims, sd)
+        self.sup = wo.suppress_token_ids(self.tok, ck.non_speech_suppress_ids())
+        self.max_new = max_new
+
+    def reset_max(self, g):
+        g.fill_(float("-inf"))
+
+    def mel_stage1(self, pcm, pcm_offset, n_file, n_total, frame0, n_frames, out, gmax):
+        full = torch.zeros(n_total)
+        full[pcm_offset:pcm_offset + pcm.numel()] = pcm          # only this rank's samples (+halo) are known
+        lm = wo.log_mel_unnormalised(full.numpy(), self.dims.n_mels)[:, frame0:frame0 + n_frames]
+        out[:, :n_frames] = lm
+        gmax.copy_(torch.maximum(gmax, lm.max().reshape(1)))
+
+    def mel_stage2(self, mel, n_frames, gmax):
+        mel[:, :n_frames] = (torch.maximum(mel[:, :n_frames], gmax - 8.0) + 4.0) / 4.0
+
+    def transcribe_mel(self, mel, n_content, w_lo, w_hi, prompt, **kw):
+        segs = []
+        for w in range(w_lo, w_hi):
+            seg = mel[:, w * N_FRAMES:min((w + 1) * N_FRAMES, max(n_content, 0))]
+            segs.append(wo.pad_or_trim_frames(seg))
+        with torch.no_grad():
+            r = wo.greedy_decode(self.om, self.om.encode(torch.stack(segs)), prompt, self.tok, self.sup, self.max_new)
+        return {"tokens": r["tokens"], "sum_logprobs": list(r["sum_logprobs"]), "no_speech_probs": list(r["no_speech_probs"]),
+                "steps": r["steps"]}
+
+
+def _worker(rank, world, port, n_samples, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    dims = ck.dims_for("micro")
+    sd = ck.synthetic_state_dict(dims, seed=0, eot_boost=3.0)
+    eng = OracleEngine(dims, sd, max_new=12)
+    audio = wo.varied_audio(21, n_samples)
+    audio[: n_samples // 3] *= 0.02          # the global mel maximum lives in rank 1's share
+    init = wo.initial_tokens(eng.tok, 0)
+    out = wdist.transcribe_sharded(eng, audio, init)
+    q.put((rank, out["tokens"], out["sum_logprobs"], out["n_windows"], out["local_windows"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_matches_single_process():
+    n_samples = 16000 * 95 + 321           # 4 windows, the last one ragged
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_samples, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    dims = ck.dims_for("micro")
+    sd = ck.synthetic_state_dict(dims, seed=0, eot_boost=3.0)
+    tok = ck.special_tokens_for(dims.n_vocab)
+    audio = wo.varied_audio(21, n_samples)
+    audio[: n_samples // 3] *= 0.02
+    with torch.no_grad():
+        ref = wo.transcribe_windows(wo.OracleWhisper(dims, sd), audio, wo.initial_tokens(tok, 0), tok,
+                                    wo.suppress_token_ids(tok, ck.non_speech_suppress_ids()), max_new_tokens=12)
+    assert ref["n_windows"] == 4
+    for rank, toks, sums, nw, local in sorted(got):
+        assert nw == 4 and local == ((0, 2) if rank == 0 else (2, 4))
+        assert toks == ref["tokens"]                      # every rank holds the full, window-ordered result
+        np.testing.assert_allclose(sums, ref["sum_logprobs"], rtol=1e-4, atol=1e-3)
+
+
+def test_single_process_path_needs_no_process_group():
+    dims = ck.dims_for("micro")
+    sd = ck.synthetic_state_dict(dims, seed=0)
+    eng = OracleEngine(dims, sd, max_new=4)
+    audio = wo.varied_audio(2, 16000 * 31)
+    out = wdist.transcribe_sharded(eng, audio, wo.initial_tokens(eng.tok, 0))
+    assert out["n_windows"] == 2 and len(out["tokens"]) == 2 and out["local_windows"] == (0, 2)
+    assert wdist.local_sample_range(10_000_000, 2, 4) == (2 * 480000 - 200, 4 * 480000 + 200)
+    assert wdist.local_sample_range(500_000, 0, 2) == (0, 500_000)

@@ -1,0 +1,144 @@
+"""Host-side logic that needs no GPU: checkpoints, token tables, tokenizer, audio helpers, the drop-in module contract
+(ref:app/transcription/speech_recognition.py:29-89; contract shape pinned by ref:tests/test_hybrid_stt.py:55,130-136)."""
+import asyncio
+import base64
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from whisper_amd import audio as wa
+from whisper_amd import checkpoint as ck
+from whisper_amd.tokenizer import LANGUAGES, Tokenizer, language_index, supported_languages
+
+
+def test_dims_and_special_tokens():
+    d = ck.dims_for("large-v3")
+    assert (d.n_audio_state, d.n_audio_head, d.n_audio_layer, d.n_text_layer, d.n_mels, d.n_vocab) == (1280, 20, 32, 32, 128, 51866)
+    assert ck.dims_for("turbo").n_text_layer == 4 and ck.dims_for("tiny").n_audio_state == 384
+    t = ck.special_tokens_for(51865)
+    assert (t.eot, t.sot, t.translate, t.transcribe, t.sot_lm, t.sot_prev, t.no_speech, t.no_timestamps, t.timestamp_begin) == \
+        (50257, 50258, 50358, 50359, 50360, 50361, 50362, 50363, 50364)
+    t3 = ck.special_tokens_for(51866)
+    assert (t3.no_timestamps, t3.timestamp_begin, t3.n_langs) == (50364, 50365, 100)
+    assert t.lang(0) == 50259 and t3.lang(99) == 50358
+    with pytest.raises(ValueError):
+        t.lang(99)
+    with pytest.raises(KeyError):
+        ck.dims_for("gigantic")
+
+
+def test_name_mapping_roundtrip_and_checkpoint_io(tmp_path):
+    dims = ck.dims_for("micro")
+    sd = ck.synthetic_state_dict(dims, seed=3)
+    assert set(sd) == set(ck.tensor_shapes(dims))
+    for k in sd:
+        assert ck.hf_to_canonical_name(ck.canonical_to_hf_name(k)) == k
+    assert ck.hf_to_canonical_name("proj_out.weight") is None
+    assert ck.dims_from_state_dict(sd) == dims
+    p = str(tmp_path / "m.pt")
+    ck.save_checkpoint(p, dims, sd)
+    d2, sd2 = ck.load_checkpoint(p)
+    assert d2 == dims and all(torch.equal(sd[k], sd2[k]) for k in sd)
+    from safetensors.torch import save_file
+    hf = {ck.canonical_to_hf_name(k): v.contiguous() for k, v in sd.items()}
+    ps = str(tmp_path / "model.safetensors")
+    save_file(hf, ps)
+    d3, sd3 = ck.load_checkpoint(ps)
+    assert d3 == dims and all(torch.equal(sd[k], sd3[k]) for k in sd)
+    with pytest.raises(FileNotFoundError):
+        ck.load_checkpoint(str(tmp_path / "missing.pt"))
+
+
+def test_synthetic_weights_are_seeded():
+    dims = ck.dims_for("micro")
+    a, b, c = ck.synthetic_state_dict(dims, 0), ck.synthetic_state_dict(dims, 0), ck.synthetic_state_dict(dims, 1)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert not torch.equal(a["decoder.token_embedding.weight"], c["decoder.token_embedding.weight"])
+    assert torch.equal(a["encoder.positional_embedding"], ck.sinusoids(1500, 128))
+
+
+def test_languages_and_tokenizer(tmp_path):
+    assert len(LANGUAGES) == 100 and list(LANGUAGES)[:3] == ["en", "zh", "de"] and list(LANGUAGES)[-1] == "yue"
+    assert len(supported_languages(51865)) == 99 and "yue" in supported_languages(51866)
+    assert language_index("ru", 51865) == 4 and language_index("Russian", 51865) == 4
+    with pytest.raises(ValueError):
+        language_index("yue", 51865)
+    tk = Tokenizer(51865)
+    assert tk.decode([10, 50257, 11, 50400]) == "<|10|><|11|>"       # ids >= eot are dropped, placeholder rendering
+    # a toy tiktoken-format vocabulary: 256 bytes + two merges
+    lines = [base64.b64encode(bytes([i])) + b" " + str(i).encode() for i in range(256)]
+    lines += [base64.b64encode(b"he") + b" 256", base64.b64encode(b" w") + b" 257", base64.b64encode(b"hel") + b" 258"]
+    vp = tmp_path / "toy.tiktoken"
+    vp.write_bytes(b"\n".join(lines) + b"\n")
+    tk = Tokenizer(51865, str(vp))
+    ids = tk.encode("hello world")
+    assert tk.decode(ids) == "hello world" and 258 in ids and 257 in ids
+    assert tk.decode([0xE2, 0x82, 0xAC]) == "€"
+
+
+def test_audio_helpers(tmp_path):
+    assert wa.n_windows(1) == 1 and wa.n_windows(480000) == 1 and wa.n_windows(480160) == 2 and wa.n_windows(16000 * 3600) == 120
+    assert wa.n_mel_frames(480000) == 6000
+    assert [wa.shard_range(120, r, 8) for r in (0, 7)] == [(0, 15), (105, 120)]
+    assert [wa.shard_range(3, r, 2) for r in (0, 1)] == [(0, 2), (2, 3)]
+    assert wa.shard_range(1, 3, 4) == (1, 1)
+    x = wa.synthetic_audio(0, 16000)
+    p = str(tmp_path / "a.wav")
+    wa.save_wav_pcm16(p, x)
+    y = wa.load_wav_pcm16(p)
+    assert y.shape == x.shape and np.abs(x - y).max() <= 1.0 / 32768 + 1e-7
+    fb = wa.slaney_mel_filterbank(80)
+    assert fb.shape == (80, 201) and (fb >= 0).all() and (fb.sum(axis=1) > 0).all()
+
+
+def _fresh_dropin(monkeypatch, **env):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    sys.modules.pop("whisper_amd.speech_recognition", None)
+    return importlib.import_module("whisper_amd.speech_recognition")
+
+
+def test_dropin_contract_without_model(monkeypatch, tmp_path):
+    monkeypatch.chdir(tmp_path)     # no config.yaml
+    sr = _fresh_dropin(monkeypatch, WHISPER_TRANSCRIPTION_WHISPER_MODEL="tiny", WHISPER_TRANSCRIPTION_LANGUAGE="ru")
+    assert sr.WHISPER_MODEL == "tiny" and sr.LANGUAGE == "ru"       # WHISPER_<SECTION>_<KEY> split("_", 2) rule
+    assert sr.whisper_model is None                                  # load failed (no GPU / no checkpoint): import survives
+    with pytest.raises(RuntimeError, match="Whisper model not initialized"):
+        asyncio.run(sr.transcribe_audio(tmp_path / "x.wav"))
+    assert sr.get_supported_languages()["en"] == "english"
+
+
+def test_dropin_result_shaping(monkeypatch, tmp_path):
+    monkeypatch.chdir(tmp_path)
+    sr = _fresh_dropin(monkeypatch)
+    calls = []
+
+    def fake_transcribe(path, language=None, prompt=None):
+        calls.append((path, language))
+        return {"text": "  тестовый текст ", "confidence": 0.95, "chunks_processed": 1, "language": "ru"}
+
+    monkeypatch.setattr(sr, "whisper_model", object())
+    monkeypatch.setattr(sr._tx, "transcribe", fake_transcribe)
+    out = asyncio.run(sr.transcribe_audio(tmp_path / "a.wav", detailed=True))
+    assert out == ("тестовый текст", 0.95, "ru") and isinstance(out[1], float)
+    out = asyncio.run(sr.transcribe_audio(tmp_path / "a.wav", detailed=False))       # privacy branch still runs the model
+    assert out == ("Voice authentication required for full transcription", 0.5, "ru") and len(calls) == 2
+
+    def boom(*a, **k):
+        raise ValueError("decode failed")
+
+    monkeypatch.setattr(sr._tx, "transcribe", boom)
+    assert asyncio.run(sr.transcribe_audio(tmp_path / "a.wav")) == ("Error during transcription", 0.0, "unknown")
+
+
+def test_transcribe_requires_configuration():
+    from whisper_amd import transcribe as tx
+    tx.close()
+    with pytest.raises(RuntimeError, match="Whisper model not initialized"):
+        tx.transcribe(np.zeros(16000, np.float32))
+    with pytest.raises(FileNotFoundError):
+        tx.configure(model="base")       # no checkpoint and synthetic weights not allowed: never downloads

@@ -1,0 +1,126 @@
+"""The CPU oracle against the committed golden vectors (tests/golden, produced by oracle/make_golden.py from the
+transformers 5.15.0 Whisper implementation).  The reference holds no fixtures for this path."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import whisper_oracle as wo
+from oracle.make_golden import prefix_tokens
+from whisper_amd import checkpoint as ck
+from whisper_amd.audio import slaney_mel_filterbank
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_mel_filters_and_log_mel_match_hf(n_mels):
+    g = np.load(os.path.join(G, f"hf_mel_{n_mels}.npz"))
+    assert np.abs(wo.mel_filters(n_mels) - g["filters"]).max() < 1e-7
+    assert np.abs(slaney_mel_filterbank(n_mels) - g["filters"]).max() < 1e-7      # the product's own generator
+    mel = wo.log_mel_spectrogram(wo.varied_audio(int(g["audio_seed"])), n_mels, padding=0).numpy()
+    assert mel.shape == (n_mels, 3000)
+    # north_star tolerance: 1e-4 relative (values span about [-0.7, 1.5])
+    assert np.abs(mel[:, ::7] - g["frames_stride7"]).max() < 1e-4 * np.abs(g["frames_stride7"]).max()
+    np.testing.assert_allclose(mel.astype(np.float64).sum(axis=1), g["row_sums"], rtol=1e-5)
+    np.testing.assert_allclose(mel.astype(np.float64).sum(axis=0)[::3], g["col_sums"], rtol=1e-4, atol=1e-3)
+
+
+def test_padded_mel_differs_from_hf_only_in_the_last_frames():
+    """Upstream pads 30 s of zeros before the STFT, HF reflects at the clip end: same values except the frames whose
+    window crosses the end."""
+    a = wo.varied_audio(3)
+    up = wo.log_mel_spectrogram(a, 80, padding=wo.N_SAMPLES)[:, :3000]
+    hf = wo.log_mel_spectrogram(a, 80, padding=0)
+    assert torch.allclose(up[:, :2998], hf[:, :2998], atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["micro", "tiny"])
+def test_encoder_and_logits_match_hf(name):
+    g = np.load(os.path.join(G, f"hf_model_{name}.npz"))
+    dims = ck.dims_for(name)
+    sd = ck.synthetic_state_dict(dims, seed=0)
+    tok = ck.special_tokens_for(dims.n_vocab)
+    om = wo.OracleWhisper(dims, sd)
+    mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(s), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000] for s in (0, 1)])
+    toks = prefix_tokens(tok)
+    assert np.array_equal(toks.numpy(), g["tokens"])
+    with torch.no_grad():
+        xa = om.encode(mels)
+        lg = om.logits(toks, xa)
+    scale = np.abs(g["enc_rows_stride50"]).max()
+    assert np.abs(xa[:, ::50].numpy() - g["enc_rows_stride50"]).max() < 2e-4 * scale     # fp32, different op order
+    np.testing.assert_allclose(xa.norm(dim=-1).numpy(), g["enc_row_norms"], rtol=2e-4)
+    lscale = np.abs(g["logits_stride97"]).max()
+    assert np.abs(lg[..., ::97].numpy() - g["logits_stride97"]).max() < 2e-4 * lscale
+    top = lg.topk(8, dim=-1)
+    assert np.array_equal(top.indices[..., 0].numpy(), g["logits_top_indices"][..., 0])     # argmax agrees with HF
+    assert np.abs(top.values.numpy() - g["logits_top_values"]).max() < 2e-4 * lscale
+
+
+@pytest.mark.parametrize("name", ["micro"])
+def test_greedy_rules_regression(name):
+    g = np.load(os.path.join(G, f"oracle_greedy_{name}.npz"))
+    dims = ck.dims_for(name)
+    sd = ck.synthetic_state_dict(dims, seed=0, eot_boost=3.0)
+    tok = ck.special_tokens_for(dims.n_vocab)
+    om = wo.OracleWhisper(dims, sd)
+    sup = wo.suppress_token_ids(tok, ck.non_speech_suppress_ids())
+    assert np.array_equal(np.asarray(sup, np.int32), g["suppress_ids"])
+    mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(s), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000] for s in range(4)])
+    with torch.no_grad():
+        xa = om.encode(mels)
+        for mode, wts, n_new in (("plain", True, 40), ("ts", False, 48)):
+            init = wo.initial_tokens(tok, 0, without_timestamps=wts)
+            assert np.array_equal(np.asarray(init, np.int32), g[f"{mode}_init"])
+            r = wo.greedy_decode(om, xa, init, tok, sup, max_new_tokens=n_new, without_timestamps=wts)
+            for b, t in enumerate(r["tokens"]):
+                want = [int(v) for v in g[f"{mode}_ids"][b] if v >= 0]
+                assert t == want
+            np.testing.assert_allclose(r["sum_logprobs"], g[f"{mode}_sum_logprobs"], rtol=1e-4, atol=1e-3)
+            assert g[f"{mode}_margins"].min() > 1e-4       # the fixture argmax is well conditioned against fp32 noise
+    lens = [(g["plain_ids"][b] >= 0).sum() for b in range(4)]
+    assert len(set(lens)) > 1, "fixture should contain sequences that end at different steps"
+
+
+def test_timestamp_rules_unit():
+    tok = ck.special_tokens_for(51865)
+    V = 51865
+    tb = tok.timestamp_begin
+    # first sampled position: only timestamps up to max_initial_timestamp survive
+    lg = torch.zeros(1, V)
+    wo.apply_timestamp_rules(lg, torch.tensor([[tok.sot, tok.lang(0), tok.transcribe]]), 3, tok)
+    assert torch.isinf(lg[0, :tb]).all() and torch.isfinite(lg[0, tb:tb + 51]).all() and torch.isinf(lg[0, tb + 51:]).all()
+    # after <ts> <text>: a timestamp earlier than the last one is forbidden
+    lg = torch.zeros(1, V)
+    lg[0, 100] = 50.0                      # a strong text token so the "timestamp mass" rule does not fire
+    wo.apply_timestamp_rules(lg, torch.tensor([[tok.sot, tok.lang(0), tok.transcribe, tb + 10, 500]]), 3, tok)
+    assert torch.isinf(lg[0, tb:tb + 11]).all() and torch.isfinite(lg[0, tb + 11]).all() and torch.isfinite(lg[0, 500])
+    # after <text> <ts>: the next token must be a timestamp or EOT
+    lg = torch.zeros(1, V)
+    wo.apply_timestamp_rules(lg, torch.tensor([[tok.sot, tok.lang(0), tok.transcribe, tb + 1, 500, tb + 20]]), 3, tok)
+    assert torch.isinf(lg[0, :tok.eot]).all()
+    # after <ts> <ts>: the next token must be text
+    lg = torch.zeros(1, V)
+    lg[0, 77] = 50.0
+    wo.apply_timestamp_rules(lg, torch.tensor([[tok.sot, tok.lang(0), tok.transcribe, tb + 1, tb + 20]]), 3, tok)
+    assert torch.isinf(lg[0, tb:]).all() and torch.isfinite(lg[0, 77])
+
+
+def test_live_against_transformers_if_available():
+    """Same check as the golden test but against the live transformers implementation (skipped where absent)."""
+    pytest.importorskip("transformers")
+    os.environ.setdefault("HF_HUB_OFFLINE", "1")
+    from oracle.make_golden import build_hf
+    dims = ck.dims_for("micro")
+    sd = ck.synthetic_state_dict(dims, seed=1)
+    hf = build_hf(dims, sd)
+    om = wo.OracleWhisper(dims, sd)
+    mel = wo.log_mel_spectrogram(wo.varied_audio(9), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000][None]
+    toks = prefix_tokens(ck.special_tokens_for(dims.n_vocab))[:1]
+    with torch.no_grad():
+        a, b = om.encode(mel), hf.model.encoder(mel).last_hidden_state
+        la, lb = om.logits(toks, a), hf(input_features=mel, decoder_input_ids=toks).logits
+    assert (a - b).abs().max() < 2e-4 * b.abs().max()
+    assert (la - lb).abs().max() < 2e-4 * lb.abs().max()

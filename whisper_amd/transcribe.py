@@ -1,0 +1,145 @@
+"""``transcribe(audio, language=None, prompt=None) -> {"text", "confidence", "chunks_processed"}`` — the north-star
+contract of the local backend (BASELINE.json), served by the MI355X engine.
+
+The reference has no function of exactly this shape (SURVEY.md §8a "observations"); its real local call is
+``transcribe_audio(audio_path, detailed)`` (ref:app/transcription/speech_recognition.py:29-79), mirrored in
+``whisper_amd/speech_recognition.py`` on top of this module.
+
+Algorithm = upstream ``Whisper.transcribe`` restricted to what the reference's call reaches, in the independent-window
+variant (a declared divergence from upstream's sequential seek loop): whole-file log-mel with 30 s of
+zero padding and a whole-file clamp, fixed 30 s windows, each decoded greedily (temperature 0, no fallback) from
+``[sot, lang, transcribe, notimestamps]``.  With several ranks (torch.distributed initialised) windows are sharded
+across GPUs (whisper_amd/dist.py).
+"""
+from __future__ import annotations
+
+import logging
+import math
+import os
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import checkpoint as ck
+from .audio import N_FRAMES, N_SAMPLES, load_wav_pcm16
+from .tokenizer import LANGUAGE_CODES, Tokenizer, language_index
+
+logger = logging.getLogger(__name__)
+
+_STATE: Dict[str, object] = {"engine": None, "tokenizer": None, "settings": None}
+
+
+def configure(model: str = "base", checkpoint: Optional[str] = None, vocab: Optional[str] = None,
+              precision: str = "bf16", max_batch: int = 16, device: Optional[int] = None,
+              allow_synthetic_weights: bool = False, confidence_mode: str = "reference", seed: int = 0):
+    """Create the process-global engine (the counterpart of the reference's module-level ``whisper.load_model``,
+    ref:speech_recognition.py:20-26).  ``checkpoint`` is a LOCAL openai ``.pt`` or HF ``.safetensors`` file; without
+    one, ``allow_synthetic_weights`` must be set explicitly (seeded random weights, for benchmarks and tests)."""
+    from .engine import WhisperEngine
+    if checkpoint:
+        dims, sd = ck.load_checkpoint(checkpoint)
+    elif allow_synthetic_weights:
+        dims = ck.dims_for(model)
+        sd = ck.synthetic_state_dict(dims, seed=seed)
+    else:
+        raise FileNotFoundError(
+            f"no local checkpoint configured for Whisper model {model!r} (this build never downloads weights); "
+            "set whisper_amd.checkpoint or allow synthetic weights")
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    close()
+    eng = WhisperEngine(dims, sd, precision=precision, max_batch=max_batch, device=device)
+    _STATE["engine"] = eng
+    _STATE["tokenizer"] = Tokenizer(dims.n_vocab, vocab)
+    _STATE["settings"] = {"model": model, "confidence_mode": confidence_mode}
+    return eng
+
+
+def close() -> None:
+    eng = _STATE.get("engine")
+    if eng is not None:
+        eng.close()
+    _STATE["engine"] = None
+
+
+def get_engine():
+    if _STATE["engine"] is None:
+        raise RuntimeError("Whisper model not initialized")
+    return _STATE["engine"]
+
+
+def get_tokenizer() -> Tokenizer:
+    if _STATE["tokenizer"] is None:
+        raise RuntimeError("Whisper model not initialized")
+    return _STATE["tokenizer"]
+
+
+def _load_audio(audio: Union[str, Path, np.ndarray, torch.Tensor]) -> np.ndarray:
+    if isinstance(audio, (str, Path)):
+        return load_wav_pcm16(str(audio))
+    if torch.is_tensor(audio):
+        audio = audio.detach().cpu().numpy()
+    a = np.asarray(audio)
+    if a.ndim != 1:
+        raise ValueError("audio must be mono (1-D float32 at 16 kHz)")
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def detect_language(engine, mel: torch.Tensor, n_content_frames: int) -> int:
+    """Upstream ``detect_language`` on the first window: one decoder step on ``[sot]``, argmax over the language
+    tokens (hf:models/whisper/generation_whisper.py:1610-1673)."""
+    engine.encode(mel, N_FRAMES, mel.stride(0), n_content_frames, 1)
+    tok = engine.tok
+    logits = engine.decoder_logits(torch.tensor([[tok.sot]], dtype=torch.int32))[0, 0]
+    langs = logits[tok.sot + 1: tok.sot + 1 + tok.n_langs]
+    return int(torch.argmax(langs).item())
+
+
+def _prompt_ids(prompt, tokenizer: Tokenizer) -> Optional[List[int]]:
+    if prompt is None or (isinstance(prompt, str) and not prompt.strip()):
+        return None
+    if isinstance(prompt, str):
+        if not tokenizer.has_vocab:
+            logger.warning("text prompt ignored: no vocabulary file configured (pass token ids instead)")
+            return None
+        return tokenizer.encode(" " + prompt.strip())
+    return [int(p) for p in prompt]
+
+
+def transcribe(audio, language: Optional[str] = None, prompt: Union[None, str, Sequence[int]] = None,
+               **decode_kw) -> Dict[str, object]:
+    """Returns ``{"text", "confidence", "chunks_processed"}`` plus ``language``, ``tokens`` (per window),
+    ``avg_logprob`` and ``no_speech_prob`` (per window).
+
+    ``confidence``: in the default ``confidence_mode="reference"`` this is 0.0 — what the reference computes, because it
+    reads a ``"confidence"`` key that openai-whisper segments do not carry (ref:speech_recognition.py:62-66).
+    ``confidence_mode="avg_logprob"`` returns ``exp(mean avg_logprob)`` instead."""
+    from . import dist as wdist
+    eng = get_engine()
+    tokenizer = get_tokenizer()
+    pcm_host = _load_audio(audio)
+    if pcm_host.shape[0] == 0:
+        return {"text": "", "confidence": 0.0, "chunks_processed": 0, "language": language or "en", "tokens": [],
+                "avg_logprob": [], "no_speech_prob": []}
+    rank, world = wdist.rank_world()
+    n_file = int(pcm_host.shape[0])
+    if language is None:
+        # language id needs the first window only; every rank computes it (identical result, no exchange needed)
+        first = torch.from_numpy(pcm_host[: min(n_file, N_SAMPLES)]).to(eng.torch_device)
+        mel0 = eng.log_mel(first)
+        lang_idx = detect_language(eng, mel0, min(n_file, N_SAMPLES) // 160)
+    else:
+        lang_idx = language_index(language, eng.dims.n_vocab)
+    init = eng.initial_tokens(lang_idx, prompt_ids=_prompt_ids(prompt, tokenizer))
+    res = wdist.transcribe_sharded(eng, pcm_host, init, **decode_kw)
+    texts = [tokenizer.decode(t) for t in res["tokens"]]
+    avg_lp = [float(s) / (len(t) + 1) for s, t in zip(res["sum_logprobs"], res["tokens"])]
+    mode = (_STATE["settings"] or {}).get("confidence_mode", "reference")
+    confidence = 0.0 if mode == "reference" or not avg_lp else float(math.exp(sum(avg_lp) / len(avg_lp)))
+    return {
+        "text": "".join(texts).strip(), "confidence": confidence, "chunks_processed": int(res["n_windows"]),
+        "language": LANGUAGE_CODES[lang_idx], "tokens": res["tokens"], "avg_logprob": avg_lp,
+        "no_speech_prob": [float(x) for x in res["no_speech_probs"]],
+    }
