@@ -1,0 +1,144 @@
+"""GPU tests of the public surface: golden fixtures through the C-ABI, transcribe(), the drop-in module, and
+size-independent properties at benchmark-like sizes."""
+import asyncio
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from whisper_amd import checkpoint as ck
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _mels(dims, seeds):
+    from oracle import whisper_oracle as wo
+    return torch.stack([wo.log_mel_spectrogram(wo.varied_audio(s), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000] for s in seeds])
+
+
+@pytest.mark.parametrize("n_mels,name", [(80, "micro"), (128, "micro128")])
+def test_mel_against_hf_golden(n_mels, name):
+    """HF features (reflect padding at the clip end) == engine mel with padding 0."""
+    from oracle import whisper_oracle as wo
+    from whisper_amd.engine import WhisperEngine
+    g = np.load(os.path.join(G, f"hf_mel_{n_mels}.npz"))
+    dims = ck.dims_for(name)
+    eng = WhisperEngine(dims, ck.synthetic_state_dict(dims, 0), precision="fp32", max_batch=1)
+    try:
+        mel = eng.log_mel(torch.from_numpy(wo.varied_audio(int(g["audio_seed"]))), padding=0).cpu().numpy()
+    finally:
+        eng.close()
+    assert mel.shape == (n_mels, 3000)
+    assert np.abs(mel[:, ::7] - g["frames_stride7"]).max() < 1e-4 * np.abs(g["frames_stride7"]).max()
+    np.testing.assert_allclose(mel.astype(np.float64).sum(axis=1), g["row_sums"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["micro", "tiny"])
+def test_model_against_hf_golden_fp32(name):
+    from whisper_amd.engine import WhisperEngine
+    g = np.load(os.path.join(G, f"hf_model_{name}.npz"))
+    dims = ck.dims_for(name)
+    eng = WhisperEngine(dims, ck.synthetic_state_dict(dims, 0), precision="fp32", max_batch=2)
+    try:
+        eng.encode_windows(_mels(dims, (0, 1)))
+        xa = eng.encoder_output(2).cpu()
+        lg = eng.decoder_logits(torch.from_numpy(g["tokens"])).cpu()
+    finally:
+        eng.close()
+    assert np.abs(xa[:, ::50].numpy() - g["enc_rows_stride50"]).max() < 2e-4 * np.abs(g["enc_rows_stride50"]).max()
+    lscale = np.abs(g["logits_stride97"]).max()
+    assert np.abs(lg[..., ::97].numpy() - g["logits_stride97"]).max() < 2e-4 * lscale
+    assert np.array_equal(lg.argmax(-1).numpy(), g["logits_top_indices"][..., 0])
+
+
+@pytest.mark.parametrize("name", ["micro", "tiny"])
+def test_greedy_against_golden_fp32(name):
+    from whisper_amd.engine import WhisperEngine
+    g = np.load(os.path.join(G, f"oracle_greedy_{name}.npz"))
+    dims = ck.dims_for(name)
+    eng = WhisperEngine(dims, ck.synthetic_state_dict(dims, 0, eot_boost=3.0), precision="fp32", max_batch=4,
+                        suppress_ids=[int(i) for i in g["suppress_ids"]])
+    try:
+        eng.encode_windows(_mels(dims, range(4)))
+        for mode, wts, n_new in (("plain", True, 40), ("ts", False, 48)):
+            init = [int(i) for i in g[f"{mode}_init"]]
+            r = eng.decode_greedy(4, init, max_new_tokens=n_new, without_timestamps=wts)
+            t, n = r["tokens"].cpu(), r["n_tokens"].cpu()
+            for b in range(4):
+                want = [int(v) for v in g[f"{mode}_ids"][b] if v >= 0]
+                assert t[b, len(init):len(init) + int(n[b])].tolist() == want
+            np.testing.assert_allclose(r["sum_logprobs"].cpu().numpy(), g[f"{mode}_sum_logprobs"], rtol=1e-4, atol=1e-3)
+            np.testing.assert_allclose(r["no_speech_probs"].cpu().numpy(), g[f"{mode}_no_speech"], rtol=1e-3)
+    finally:
+        eng.close()
+
+
+def test_transcribe_contract_and_dropin(tmp_path, monkeypatch):
+    from oracle import whisper_oracle as wo
+    from whisper_amd import audio as wa
+    from whisper_amd import transcribe as tx
+    eng = tx.configure(model="micro", precision="fp32", max_batch=2, allow_synthetic_weights=True)
+    try:
+        audio = wo.varied_audio(4, 16000 * 65)
+        out = tx.transcribe(audio, language="en", max_new_tokens=8)
+        assert set(out) >= {"text", "confidence", "chunks_processed"}
+        assert out["chunks_processed"] == 3 and isinstance(out["text"], str) and out["confidence"] == 0.0
+        assert len(out["tokens"]) == 3 and all(len(t) <= 8 for t in out["tokens"])
+        # a path gives the same ids as the array it was written from (up to PCM16 quantisation the ids may differ, so
+        # compare against the quantised array)
+        p = str(tmp_path / "clip.wav")
+        wa.save_wav_pcm16(p, audio)
+        q = wa.load_wav_pcm16(p)
+        assert tx.transcribe(p, language="en", max_new_tokens=8)["tokens"] == tx.transcribe(q, language="en", max_new_tokens=8)["tokens"]
+        # language auto-detection = argmax over the language tokens of one decoder step on [sot]
+        om = wo.OracleWhisper(eng.dims, ck.synthetic_state_dict(eng.dims, 0))
+        with torch.no_grad():
+            mel = wo.log_mel_spectrogram(audio[:wo.N_SAMPLES], eng.dims.n_mels, padding=wo.N_SAMPLES)[:, :3000]
+            lg = om.logits(torch.tensor([[eng.tok.sot]]), om.encode(mel[None]))[0, 0]
+        want = int(lg[eng.tok.sot + 1: eng.tok.sot + 1 + eng.tok.n_langs].argmax())
+        from whisper_amd.tokenizer import LANGUAGE_CODES
+        assert tx.transcribe(audio, max_new_tokens=2)["language"] == LANGUAGE_CODES[want]
+        # the drop-in module on top of the same engine
+        import whisper_amd.speech_recognition as sr
+        monkeypatch.setattr(sr, "whisper_model", eng)
+        monkeypatch.setattr(sr, "LANGUAGE", "en")
+        text, conf, lang = asyncio.run(sr.transcribe_audio(p, detailed=True))
+        assert (conf, lang) == (0.0, "en") and isinstance(text, str)
+        assert asyncio.run(sr.transcribe_audio(p, detailed=False))[0] == "Voice authentication required for full transcription"
+        assert asyncio.run(sr.transcribe_audio(tmp_path / "missing.wav")) == ("Error during transcription", 0.0, "unknown")
+    finally:
+        tx.close()
+
+
+def test_properties_at_scale_bf16():
+    """Size-independent properties on a base-size model at batch 16 (BASELINE configs[1] shape): window results do not
+    depend on the batch they were decoded in, nor on graph vs eager launches; rows are EOT padded; mel is window-local
+    away from the clamp."""
+    from whisper_amd.audio import synthetic_audio
+    from whisper_amd.engine import WhisperEngine
+    dims = ck.dims_for("base")
+    eng = WhisperEngine(dims, ck.synthetic_state_dict(dims, 0, eot_boost=3.0), precision="bf16", max_batch=16)
+    try:
+        pcm = torch.from_numpy(np.concatenate([synthetic_audio(s) for s in range(16)])).cuda()
+        mel = eng.log_mel(pcm)
+        init = eng.initial_tokens(0)
+        content = pcm.numel() // 160
+        eng.encode(mel, 3000, mel.stride(0), content, 16)
+        a = eng.decode_greedy(16, init, max_new_tokens=24, use_graph=True)
+        ta, na = a["tokens"].cpu(), a["n_tokens"].cpu()
+        b = eng.decode_greedy(16, init, max_new_tokens=24, use_graph=False)
+        assert torch.equal(ta, b["tokens"].cpu()) and torch.equal(na, b["n_tokens"].cpu())
+        # windows 4..7 decoded alone give the same ids as inside the batch of 16
+        view = mel[:, 4 * 3000:]
+        eng.encode(view, 3000, mel.stride(0), content - 4 * 3000, 4)
+        c = eng.decode_greedy(4, init, max_new_tokens=24)
+        assert torch.equal(c["tokens"].cpu(), ta[4:8])
+        for r in range(16):
+            assert (ta[r, len(init) + int(na[r]):] == eng.tok.eot).all()
+        # the same clip at a different position of the file has the same mel (only the clamp is global)
+        m2 = eng.log_mel(pcm[: 2 * 480000])
+        assert torch.allclose(m2[:, 100:2900], mel[:, 100:2900], atol=1e-6)
+    finally:
+        eng.close()
