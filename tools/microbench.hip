@@ -58,16 +58,28 @@ int main(int argc, char** argv) {
         hipLaunchKernelGGL(fill_f32, dim3(64), dim3(256), 0, st, bias, (size_t)s.N, 0.1f);
         hipLaunchKernelGGL(fill_f32, dim3(64), dim3(256), 0, st, res, (size_t)64 * s.N, 1.0f);
         CK(hipStreamSynchronize(st));
-        auto body = [&] {
-            for (int l = 0; l < copies; ++l) {
-                GemmArgs g; g.A = X; g.lda = s.K; g.W = W + (size_t)l * s.N * s.K; g.ldw = s.K; g.M = M; g.N = s.N; g.K = s.K; g.in_dtype = DT_BF16;
-                g.ep.bias = bias; g.ep.out = outb; g.ep.out_dtype = DT_BF16; g.ep.ldo = s.N;
-                if (launch_gemm(g, st)) { printf("launch_gemm failed\n"); exit(1); }
+        float* part; CK(hipMalloc(&part, (size_t)16 * 64 * s.N * 4));
+        const int auto_split = decode_gemm_split(s.N, s.K);
+        for (int S : {1, 2, 4, 5, 8, 10, 16}) {
+            if (s.K % S) continue;
+            auto body = [&] {
+                for (int l = 0; l < copies; ++l) {
+                    GemmArgs g; g.A = X; g.lda = s.K; g.W = W + (size_t)l * s.N * s.K; g.ldw = s.K; g.M = M; g.N = s.N; g.K = s.K; g.in_dtype = DT_BF16;
+                    g.ep.bias = bias; g.ep.out = outb; g.ep.out_dtype = DT_BF16; g.ep.ldo = s.N;
+                    g.n_split = S; g.partial = part;
+                    if (launch_gemm(g, st)) { printf("launch_gemm failed\n"); exit(1); }
+                }
+            };
+            {   // probe: unsupported slice lengths are rejected by launch_gemm
+                GemmArgs g; g.A = X; g.lda = s.K; g.W = W; g.ldw = s.K; g.M = M; g.N = s.N; g.K = s.K; g.in_dtype = DT_BF16;
+                g.ep.out = outb; g.ep.out_dtype = DT_BF16; g.ep.ldo = s.N; g.n_split = S; g.partial = part;
+                if (launch_gemm(g, st)) continue;
             }
-        };
-        const float us = time_graph(st, copies, 20, body);
-        const double bytes = (double)s.N * s.K * 2;
-        printf("gemm %-12s N=%5d K=%4d: %7.2f us/launch  %7.1f GB/s weights\n", s.name, s.N, s.K, us, bytes / us * 1e-3);
+            const float us = time_graph(st, copies, 20, body);
+            const double bytes = (double)s.N * s.K * 2;
+            printf("gemm %-12s N=%5d K=%4d S=%2d%s: %7.2f us/launch  %7.1f GB/s weights\n", s.name, s.N, s.K, S, S == auto_split ? "*" : " ", us, bytes / us * 1e-3);
+        }
+        CK(hipFree(part));
         CK(hipFree(W)); CK(hipFree(X)); CK(hipFree(bias)); CK(hipFree(res)); CK(hipFree(outb));
     }
     {
@@ -77,6 +89,9 @@ int main(int argc, char** argv) {
         hipLaunchKernelGGL(fill_f32, dim3(8), dim3(256), 0, st, bt, (size_t)d, 1.0f);
         CK(hipStreamSynchronize(st));
         printf("layernorm 64x1280       : %.2f us/launch\n", time_graph(st, 64, 20, [&] { for (int i = 0; i < 64; ++i) launch_layernorm(x, gmm, bt, o, DT_BF16, M, d, st); }));
+        float* part; CK(hipMalloc(&part, (size_t)16 * 64 * d * 4)); CK(hipMemset(part, 0, (size_t)16 * 64 * d * 4));
+        for (int S : {0, 1, 4, 5, 8, 10})
+            printf("reduce+layernorm S=%2d   : %.2f us/launch\n", S, time_graph(st, 64, 20, [&] { for (int i = 0; i < 64; ++i) launch_reduce_layernorm(x, part, S, bt, gmm, bt, o, DT_BF16, M, d, st); }));
     }
     return 0;
 }

@@ -79,20 +79,60 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     const int n_keys = a.d_pos ? t_cur + 1 : a.n_keys;
 
     float qf[EPL];
-    {
+    if (a.q_partial) {
+        // query = consumer-side reduction of its projection GEMM's split-K partial tiles (fixed order)
+        const int c0 = h * HEAD_DIM + sub * EPL;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) qf[e] = a.q_bias[c0 + e];
+        for (int s = 0; s < a.q_nsplit; ++s) {
+            const float* pp = a.q_partial + ((int64_t)s * a.B + b) * a.q_sb + c0;
+#pragma unroll
+            for (int e = 0; e < EPL; e += 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(pp + e);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qf[e + j] += t[j];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) qf[e] = (float)(T)(qf[e] * a.q_scale);   // same rounding point as a stored query
+    } else {
         const T* qp = reinterpret_cast<const T*>(a.Q) + (int64_t)b * a.q_sb + h * a.q_sh + sub * EPL;
         C::unpack(*reinterpret_cast<const typename C::Raw*>(qp), qf);
     }
     const T* knew = nullptr; const T* vnew = nullptr;
+    typename C::Raw kn_r = {}, vn_r = {};       // this step's key/value chunk when it arrives as split-K partial tiles
+    const bool new_from_partial = PAGED && a.q_partial != nullptr;
     if (PAGED) {
-        knew = reinterpret_cast<const T*>(a.Knew) + (int64_t)b * a.new_sb + h * HEAD_DIM + sub * EPL;
-        vnew = reinterpret_cast<const T*>(a.Vnew) + (int64_t)b * a.new_sb + h * HEAD_DIM + sub * EPL;
+        if (new_from_partial) {
+            // fused q|k|v projection: k at column d_model + h*64 (scaled like q, no bias), v at 2*d_model + h*64 (bias, unscaled)
+            const int dm = a.H * HEAD_DIM, c0 = h * HEAD_DIM + sub * EPL;
+            float kf[EPL], vf[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) { kf[e] = a.q_bias[dm + c0 + e]; vf[e] = a.q_bias[2 * dm + c0 + e]; }
+            for (int s = 0; s < a.q_nsplit; ++s) {
+                const float* pp = a.q_partial + ((int64_t)s * a.B + b) * a.q_sb + c0;
+#pragma unroll
+                for (int e = 0; e < EPL; e += 4) {
+                    const f32x4 tk = *reinterpret_cast<const f32x4*>(pp + dm + e), tv = *reinterpret_cast<const f32x4*>(pp + 2 * dm + e);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { kf[e + j] += tk[j]; vf[e + j] += tv[j]; }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) kf[e] *= a.q_scale;
+            kn_r = C::pack(kf); vn_r = C::pack(vf);
+        } else {
+            knew = reinterpret_cast<const T*>(a.Knew) + (int64_t)b * a.new_sb + h * HEAD_DIM + sub * EPL;
+            vnew = reinterpret_cast<const T*>(a.Vnew) + (int64_t)b * a.new_sb + h * HEAD_DIM + sub * EPL;
+            kn_r = *reinterpret_cast<const typename C::Raw*>(knew);
+            vn_r = *reinterpret_cast<const typename C::Raw*>(vnew);
+        }
         if (split == 0 && wid == 0 && lane < LPK) {
             // append this step's key/value row to the page of position t_cur
             const int page = a.page_table[b * a.pt_ld + t_cur / KV_PAGE];
             const int64_t off = (((int64_t)page * a.H + h) * KV_PAGE + t_cur % KV_PAGE) * HEAD_DIM + sub * EPL;
-            *reinterpret_cast<typename C::Raw*>(reinterpret_cast<T*>(a.Kpool) + off) = *reinterpret_cast<const typename C::Raw*>(knew);
-            *reinterpret_cast<typename C::Raw*>(reinterpret_cast<T*>(a.Vpool) + off) = *reinterpret_cast<const typename C::Raw*>(vnew);
+            *reinterpret_cast<typename C::Raw*>(reinterpret_cast<T*>(a.Kpool) + off) = kn_r;
+            *reinterpret_cast<typename C::Raw*>(reinterpret_cast<T*>(a.Vpool) + off) = vn_r;
         }
     }
     const T* kbase = nullptr; const T* vbase = nullptr;
@@ -116,19 +156,19 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
             if (key > n_keys - 1) key = n_keys - 1;
             const T* kp; const T* vp;
             if (PAGED) {
-                if (key == t_cur) { kp = knew; vp = vnew; }
-                else {
-                    const int page = a.page_table[b * a.pt_ld + key / KV_PAGE];
-                    const int64_t off = (((int64_t)page * a.H + h) * KV_PAGE + key % KV_PAGE) * HEAD_DIM + sub * EPL;
-                    kp = reinterpret_cast<const T*>(a.Kpool) + off;
-                    vp = reinterpret_cast<const T*>(a.Vpool) + off;
-                }
+                // the row of position t_cur is being appended by this launch: its slot is read (address valid, value
+                // ignored) and replaced by the register copy below
+                const int page = a.page_table[b * a.pt_ld + key / KV_PAGE];
+                const int64_t off = (((int64_t)page * a.H + h) * KV_PAGE + key % KV_PAGE) * HEAD_DIM + sub * EPL;
+                kp = reinterpret_cast<const T*>(a.Kpool) + off;
+                vp = reinterpret_cast<const T*>(a.Vpool) + off;
             } else {
                 kp = kbase + (int64_t)key * HEAD_DIM;
                 vp = vbase + (int64_t)key * HEAD_DIM;
             }
             kr[u] = __builtin_nontemporal_load(reinterpret_cast<const typename C::Raw*>(kp));
             vr[u] = __builtin_nontemporal_load(reinterpret_cast<const typename C::Raw*>(vp));
+            if (PAGED && key == t_cur) { kr[u] = kn_r; vr[u] = vn_r; }
         }
         float s[U];
         float mt = -INFINITY;
@@ -317,7 +357,8 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnArgs a) {
 }
 
 static int check_common(const AttnArgs& a) {
-    if (a.B <= 0 || a.H <= 0 || !a.Q || !a.O) return -1;
+    if (a.B <= 0 || a.H <= 0 || (!a.Q && !a.q_partial) || !a.O) return -1;
+    if (a.q_partial && (!a.q_bias || a.q_nsplit < 1 || a.q_sb % 4 != 0)) return -1;
     const size_t es = dtype_size(a.dt);
     if ((a.q_sb * es) % 16 || (a.q_sq * es) % 16 || (a.q_sh * es) % 16 || (a.o_sb * es) % 16 || (a.o_sq * es) % 16 || (a.o_sh * es) % 16 || (a.kv_sbh * es) % 16 || (a.new_sb * es) % 16) return -1;
     return 0;
@@ -327,7 +368,7 @@ int launch_attn_decode(const AttnArgs& a, hipStream_t st) {
     if (check_common(a)) return -1;
     if (a.n_q != 1 || a.n_split < 1) return -1;
     const bool paged = a.page_table != nullptr;
-    if (paged && (!a.d_pos || !a.Kpool || !a.Vpool || !a.Knew || !a.Vnew)) return -1;
+    if (paged && (!a.d_pos || !a.Kpool || !a.Vpool || (!a.q_partial && (!a.Knew || !a.Vnew)))) return -1;
     if (!paged && (!a.K || !a.V || a.n_keys <= 0)) return -1;
     if (a.n_split > 1 && !a.partial) return -1;
     dim3 grid(a.B * a.H, a.n_split), block(256);
@@ -345,7 +386,7 @@ int launch_attn_decode(const AttnArgs& a, hipStream_t st) {
 
 int launch_attn_rows(const AttnArgs& a, hipStream_t st) {
     if (check_common(a)) return -1;
-    if (!a.K || !a.V || a.n_keys <= 0 || a.n_q <= 0) return -1;
+    if (!a.Q || !a.K || !a.V || a.n_keys <= 0 || a.n_q <= 0) return -1;
     constexpr int NQ = 4;
     dim3 grid(a.B * a.H, (a.n_q + 4 * NQ - 1) / (4 * NQ)), block(256);
     if (a.dt == DT_BF16) hipLaunchKernelGGL((attn_rows_kernel<bf16, NQ, 4>), grid, block, 0, st, a);

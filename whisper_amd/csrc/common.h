@@ -57,14 +57,24 @@ struct GemmArgs {
     int64_t ldw = 0;
     int M = 0, N = 0, K = 0;
     int in_dtype = DT_F32;              // dtype of A and W
+    // bf16, M <= 64 only: split K over n_split workgroups; raw fp32 partial tiles go to partial[split][M][N] and the
+    // epilogue is NOT applied (the consumer adds the partials, bias, scale, residual itself)
+    int n_split = 1;
+    float* partial = nullptr;
     GemmEpilogue ep;
 };
 // Returns 0 or a negative wx_status. Chooses the kernel from (dtype, M).
 int launch_gemm(const GemmArgs& g, hipStream_t st);
+// K-split factor that fills the chip for a bf16 decode GEMM (M <= 64) whose consumer can add partial tiles; 1 = none.
+int decode_gemm_split(int N, int K);
 
 // ---- elementwise / norms ---------------------------------------------------------------------------
 int launch_layernorm(const float* x, const float* gamma, const float* beta, void* out, int out_dtype,
                      int rows, int d, hipStream_t st);
+// x[r][:] += bias + sum_s partial[s][r][:] (fixed order), written back, then LayerNorm(x) -> out.  Consumer side of a
+// split-K decode GEMM whose epilogue is "residual add" (n_split == 0: plain LayerNorm, x untouched).
+int launch_reduce_layernorm(float* x, const float* partial, int n_split, const float* bias, const float* gamma,
+                            const float* beta, void* out, int out_dtype, int rows, int d, hipStream_t st);
 // x[b][:] = tok_emb[tokens[b*ld_tok + *d_pos]][:] + pos_emb[*d_pos][:]   (fp32 out; embedding tables in `dt`)
 int launch_embed(const void* tok_emb, const void* pos_emb, int dt, const int32_t* tokens, int ld_tok,
                  const int32_t* d_pos, float* x, int B, int d, hipStream_t st);
@@ -96,6 +106,9 @@ struct AttnArgs {
     // queries: q(b, iq, h) at Q + b*q_sb + iq*q_sq + h*q_sh
     const void* Q = nullptr; int64_t q_sb = 0, q_sq = 0, q_sh = HEAD_DIM;
     int n_q = 1;                         // queries per (b, h)
+    // decode only: the query as split-K partial tiles of its projection GEMM (Q == nullptr):
+    // q(b, h)[c] = (q_bias[h*64 + c] + sum_s q_partial[(s*B + b)*q_sb + h*64 + c]) * q_scale
+    const float* q_partial = nullptr; const float* q_bias = nullptr; int q_nsplit = 0; float q_scale = 1.f;
     // dense keys/values: K + (b*H + h)*kv_sbh + t*64
     const void* K = nullptr; const void* V = nullptr; int64_t kv_sbh = 0;
     int n_keys = 0;                      // dense key count (ignored when d_pos != nullptr)

@@ -70,6 +70,91 @@ int launch_layernorm(const float* x, const float* gamma, const float* beta, void
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// Consumer side of a split-K decode GEMM with a residual epilogue: x += bias + sum_s partial[s] (fixed order, so the
+// result is deterministic), then the next sub-layer's LayerNorm of the updated row.  One WORKGROUP per row (a decode
+// batch has <= 64 rows, and a CU sustains only ~25 GB/s of loads: the n_split*d*4 bytes of a row are spread over as
+// many CUs as there are rows), 16 B per lane, two-pass statistics through LDS.
+template <typename TO>
+__global__ __launch_bounds__(256) void reduce_layernorm_kernel(float* __restrict__ x, const float* __restrict__ partial, int n_split,
+                                                               const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, TO* __restrict__ out, int rows, int d) {
+    constexpr int MAXV = 2;                       // d <= 256 * 4 * 2 = 2048
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, row = blockIdx.x;
+    f32x4* xr = reinterpret_cast<f32x4*>(x + (int64_t)row * d);
+    const int nv = d / 4;
+    f32x4 v[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = tid + i * 256;
+        v[i] = (c < nv) ? xr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (n_split > 0) {
+        const f32x4* br = reinterpret_cast<const f32x4*>(bias);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = tid + i * 256;
+            if (c < nv) {
+                f32x4 t = reinterpret_cast<const f32x4*>(partial + (int64_t)row * d)[c];
+                for (int s = 1; s < n_split; ++s) t += reinterpret_cast<const f32x4*>(partial + ((int64_t)s * rows + row) * d)[c];
+                v[i] += t + br[c];
+                xr[c] = v[i];
+            }
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    if (lane == 0) red[wid] = sum;
+    __syncthreads();
+    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)d;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = tid + i * 256;
+        if (c < nv) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float t = v[i][j] - mean; sq = fmaf(t, t, sq); }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off);
+    if (lane == 0) red[4 + wid] = sq;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf(((red[4] + red[5]) + (red[6] + red[7])) / (float)d + 1e-5f);
+    const f32x4* gr = reinterpret_cast<const f32x4*>(gamma);
+    const f32x4* be = reinterpret_cast<const f32x4*>(beta);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = tid + i * 256;
+        if (c < nv) {
+            const f32x4 gg = gr[c], bb = be[c];
+            f32x4 y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = (v[i][j] - mean) * rstd * gg[j] + bb[j];
+            if constexpr (sizeof(TO) == 4) {
+                reinterpret_cast<f32x4*>(out + (int64_t)row * d)[c] = y;
+            } else {
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (bf16)y[j];
+                reinterpret_cast<bf16x4*>(out + (int64_t)row * d)[c] = o;
+            }
+        }
+    }
+}
+
+int launch_reduce_layernorm(float* x, const float* partial, int n_split, const float* bias, const float* gamma, const float* beta,
+                            void* out, int out_dtype, int rows, int d, hipStream_t st) {
+    if (d % 4 != 0 || d > 2048 || rows <= 0 || n_split < 0 || (n_split > 0 && (!partial || !bias))) return -1;
+    const int blocks = rows;
+    if (out_dtype == DT_F32) hipLaunchKernelGGL(reduce_layernorm_kernel<float>, dim3(blocks), dim3(256), 0, st, x, partial, n_split, bias, gamma, beta, (float*)out, rows, d);
+    else hipLaunchKernelGGL(reduce_layernorm_kernel<bf16>, dim3(blocks), dim3(256), 0, st, x, partial, n_split, bias, gamma, beta, (bf16*)out, rows, d);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // token + positional embedding for the current decode position
 // ---------------------------------------------------------------------------------------------------------

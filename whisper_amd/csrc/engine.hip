@@ -77,7 +77,7 @@ struct wx_engine {
     float* dx = nullptr; void *dxn = nullptr, *dqkv = nullptr, *datt = nullptr, *dhid = nullptr, *dq = nullptr;
     float* logits = nullptr;
     int32_t *tokens = nullptr, *d_pos = nullptr, *d_counter = nullptr, *n_finished = nullptr, *n_tokens = nullptr;
-    float *sum_logprob = nullptr, *no_speech = nullptr, *partial = nullptr;
+    float *sum_logprob = nullptr, *no_speech = nullptr, *partial = nullptr, *gpartial = nullptr;
     int32_t* h_pinned = nullptr;
     int encoded_B = 0;
 
@@ -427,6 +427,7 @@ int wx_finalize(wx_engine* e) {
     if ((r = A((void**)&e->sum_logprob, (size_t)B * 4))) return r;
     if ((r = A((void**)&e->no_speech, (size_t)B * 4))) return r;
     if ((r = A((void**)&e->partial, (size_t)B * e->Ht * 8 * (HEAD_DIM + 2) * 4))) return r;
+    if ((r = A((void**)&e->gpartial, (size_t)16 * B * 3 * d * 4))) return r;   // split-K partial tiles of the decode GEMMs
     HIP_TRY(hipHostMalloc((void**)&e->h_pinned, 64));
     HIP_TRY(hipDeviceSynchronize());
     e->finalized = true;
@@ -550,7 +551,8 @@ int wx_get_encoder_output(wx_engine* e, int32_t B, float* d_out, void* stream) {
 }
 
 // one decoder step for position *d_pos (all launches read the position from device memory -> graph-replayable)
-static int decode_step(wx_engine* e, int B, const SamplerArgs& sa, hipStream_t st) {
+// fp32 ("token-exact") sequence: every GEMM applies its own epilogue, LayerNorm is a separate kernel.
+static int decode_step_f32(wx_engine* e, int B, const SamplerArgs& sa, hipStream_t st) {
     const int d = e->d, dtp = e->dt, T = e->T;
     const size_t es = dtype_size(dtp);
     const wx_config& c = e->cfg;
@@ -625,6 +627,82 @@ static int decode_step(wx_engine* e, int B, const SamplerArgs& sa, hipStream_t s
     }
     WX_TRY(launch_sampler(sa, st));
     return 0;
+}
+
+// bf16 sequence (B <= 64): the three residual GEMMs of a layer and the cross-attention query projection split K over
+// workgroups and hand raw fp32 partial tiles to their consumer -- the next LayerNorm (reduce + bias + residual + LN in
+// one kernel) or the cross-attention kernel's query load -- so every weight byte streams once with the whole chip
+// pulling, and no launch is added.  11 launches per layer.
+static int decode_step_bf16(wx_engine* e, int B, const SamplerArgs& sa, hipStream_t st) {
+    const int d = e->d, dtp = e->dt, T = e->T;
+    const size_t es = dtype_size(dtp);
+    const wx_config& c = e->cfg;
+    WX_TRY(launch_embed(e->tok_emb, e->dec_pos, dtp, e->tokens, c.n_text_ctx, e->d_pos, e->dx, B, d, st));
+    const size_t cross_layer = (size_t)c.max_batch * e->Ht * T * HEAD_DIM;
+    const size_t self_layer = (size_t)c.max_batch * e->n_pages_seq * e->Ht * KV_PAGE * HEAD_DIM;
+    int n_split = 1;
+    while (n_split < 6 && B * e->Ht * n_split < 512) ++n_split;
+    const int s_dd = decode_gemm_split(d, d), s_fc2 = decode_gemm_split(d, 4 * d), s_qkv = decode_gemm_split(3 * d, d);
+    int pend_split = 0; const float* pend_bias = nullptr;       // residual update not yet folded into dx
+    auto split_gemm = [&](const void* A, int64_t lda, const void* W, int K, int S) {
+        GemmArgs g = gemm_basic(e, A, lda, W, B, d, K);
+        g.n_split = S; g.partial = e->gpartial;
+        if (S == 1) { g.ep.out = e->gpartial; g.ep.out_dtype = DT_F32; g.ep.ldo = d; }   // one "partial": same consumer path
+        return launch_gemm(g, st);
+    };
+    for (int i = 0; i < c.n_text_layer; ++i) {
+        const LayerW& L = e->dec[i];
+        WX_TRY(launch_reduce_layernorm(e->dx, e->gpartial, pend_split, pend_bias, L.ln1_g, L.ln1_b, e->dxn, dtp, B, d, st));
+        {   // fused q|k|v projection, split K: the self-attention kernel adds the partial tiles, bias and scale itself
+            GemmArgs g = gemm_basic(e, e->dxn, d, L.self.wqkv, B, 3 * d, d);
+            g.n_split = s_qkv; g.partial = e->gpartial;
+            if (s_qkv == 1) { g.ep.out = e->gpartial; g.ep.out_dtype = DT_F32; g.ep.ldo = 3 * d; }
+            WX_TRY(launch_gemm(g, st));
+        }
+        {
+            AttnArgs a;
+            a.dt = dtp; a.q_partial = e->gpartial; a.q_bias = L.self.bqkv; a.q_nsplit = s_qkv; a.q_scale = e->qk_scale; a.q_sb = 3 * d; a.n_q = 1;
+            a.page_table = e->page_table; a.pt_ld = e->n_pages_seq;
+            a.Kpool = (char*)e->selfK + self_layer * i * es; a.Vpool = (char*)e->selfV + self_layer * i * es;
+            a.d_pos = e->d_pos; a.O = e->datt; a.o_sb = d; a.B = B; a.H = e->Ht; a.n_split = 1;
+            WX_TRY(launch_attn_decode(a, st));
+        }
+        WX_TRY(split_gemm(e->datt, d, L.self.wo, d, s_dd));
+        WX_TRY(launch_reduce_layernorm(e->dx, e->gpartial, s_dd, L.self.bo, L.lnx_g, L.lnx_b, e->dxn, dtp, B, d, st));
+        WX_TRY(split_gemm(e->dxn, d, L.xq, d, s_dd));
+        {
+            AttnArgs a;
+            a.dt = dtp; a.q_partial = e->gpartial; a.q_bias = L.xbq; a.q_nsplit = s_dd; a.q_scale = e->qk_scale; a.q_sb = d; a.n_q = 1;
+            a.K = (char*)e->crossK + cross_layer * i * es; a.V = (char*)e->crossV + cross_layer * i * es;
+            a.kv_sbh = (int64_t)T * HEAD_DIM; a.n_keys = T;
+            a.O = e->datt; a.o_sb = d; a.B = B; a.H = e->Ht; a.n_split = n_split; a.partial = e->partial;
+            const bool prof = e->prof_on && e->prof_used + 2 <= e->prof_events.size();
+            if (prof) HIP_TRY(hipEventRecord(e->prof_events[e->prof_used], st));
+            WX_TRY(launch_attn_decode(a, st));
+            if (prof) { HIP_TRY(hipEventRecord(e->prof_events[e->prof_used + 1], st)); e->prof_used += 2; }
+        }
+        WX_TRY(split_gemm(e->datt, d, L.xo, d, s_dd));
+        WX_TRY(launch_reduce_layernorm(e->dx, e->gpartial, s_dd, L.xbo, L.ln2_g, L.ln2_b, e->dxn, dtp, B, d, st));
+        {
+            GemmArgs g = gemm_basic(e, e->dxn, d, L.w1, B, 4 * d, d);
+            g.ep.bias = L.b1; g.ep.act = 1; g.ep.out = e->dhid; g.ep.out_dtype = dtp; g.ep.ldo = 4 * d;
+            WX_TRY(launch_gemm(g, st));
+        }
+        WX_TRY(split_gemm(e->dhid, 4 * d, L.w2, 4 * d, s_fc2));
+        pend_split = s_fc2; pend_bias = L.b2;
+    }
+    WX_TRY(launch_reduce_layernorm(e->dx, e->gpartial, pend_split, pend_bias, e->declnf_g, e->declnf_b, e->dxn, dtp, B, d, st));
+    {
+        GemmArgs g = gemm_basic(e, e->dxn, d, e->tok_emb, B, e->vocab_pad, d);
+        g.ep.out = e->logits; g.ep.out_dtype = DT_F32; g.ep.ldo = e->vocab_pad;
+        WX_TRY(launch_gemm(g, st));
+    }
+    WX_TRY(launch_sampler(sa, st));
+    return 0;
+}
+
+static int decode_step(wx_engine* e, int B, const SamplerArgs& sa, hipStream_t st) {
+    return (e->dt == DT_BF16 && B <= 64) ? decode_step_bf16(e, B, sa, st) : decode_step_f32(e, B, sa, st);
 }
 
 static SamplerArgs make_sampler(wx_engine* e, int B, const wx_decode_opts& o, int forced) {

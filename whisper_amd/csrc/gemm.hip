@@ -3,8 +3,8 @@
 // Three kernels, one epilogue:
 //   gemm_bf16_tile   128x128x64 block tile, 4 waves (2x2), v_mfma_f32_16x16x32_bf16, XOR-swizzled LDS image,
 //                    register-staged prefetch of the next K tile.  Encoder GEMMs (M = B*1500).       [MFMA-bound]
-//   gemm_bf16_skinny M <= 64 decode GEMMs: one wave per 16 output columns streams its weight rows straight to
-//                    VGPRs (no LDS round trip for once-read weights), 4 MFMA row tiles.               [HBM-bound]
+//   gemm_bf16_decode M <= 64 decode GEMMs: weights stream once from HBM straight to VGPRs, the activation slice is
+//                    shared through LDS, optional split-K with consumer-side reduction.     [HBM/latency-bound]
 //   gemm_f32_tile    fp32 "token-exact" mode on v_mfma_f32_16x16x4_f32 (bitwise a k-ordered fmaf chain).
 // The MFMA operands are swapped (W is the A operand, the activation the B operand) so each lane ends up with 4
 // CONSECUTIVE output columns of one row: bias/GELU/residual/positional adds and the stores are 8/16-byte vectors.
@@ -156,91 +156,142 @@ __global__ __launch_bounds__(256) void gemm_bf16_tile_kernel(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// bf16 skinny (M <= 64): decode-time weight streaming.
-// One workgroup owns 16 output columns; its 4 waves split K four ways (in-workgroup split-K, reduced through LDS in a
-// fixed order, so results are deterministic).  Weight rows and activation fragments go straight from global memory
-// to VGPRs as MFMA operands; loads are software-pipelined two groups (4 k-steps of 32) deep so ~20 KB per wave are
-// in flight while the previous group's MFMAs issue.
+// bf16 decode GEMM (M <= 64): the weight matrix is read exactly once, straight from HBM to VGPRs as the MFMA A operand.
+// A decode step at batch 64 reads 3-13 MB per GEMM: less than one HBM round trip per CU, so the kernel is built around
+// latency, not bandwidth:
+//   * one workgroup = 4 waves = 64 output columns (16 per wave) x all M rows x one K slice [split*Kb, (split+1)*Kb);
+//   * the activation slice is staged through LDS in chunks of CKS*32 k (full 128-B lines, coalesced; rows padded by 32 B so
+//     the ds_read_b128 B-fragment reads are conflict-free) and shared by the 4 waves: L2 sees each activation byte once per
+//     workgroup instead of once per 16 columns;
+//   * all weight loads of a chunk (CKS x 16 B per lane) are issued before the first MFMA and the next chunk's loads are
+//     issued before the current chunk's MFMAs, so a wave keeps up to 2*CKS KiB in flight;
+//   * no load sits under a branch (the last chunk is peeled instead of predicated);
+//   * n_split > 1: K is split across workgroups and raw fp32 partial tiles go to partial[split][M][N]; the CONSUMER kernel
+//     (reduce + LayerNorm, or the attention kernel's query load) adds them in a fixed order, so there is no atomics, no
+//     fence and no extra launch, and results are deterministic.
 // ---------------------------------------------------------------------------------------------------------
-template <int MT>
-struct SkinnyFrag { bf16x8 w[2]; bf16x8 x[MT][2]; };
+constexpr int DG_BN = 64;
 
-template <int MT>
-__device__ __forceinline__ void skinny_load(SkinnyFrag<MT>& f, const bf16* wp, const bf16* const (&xp)[MT], int k) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) f.w[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + k + u * 32));
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) f.x[i][u] = *reinterpret_cast<const bf16x8*>(xp[i] + k + u * 32);
-}
-template <int MT>
-__device__ __forceinline__ void skinny_mma(const SkinnyFrag<MT>& f, f32x4 (&acc)[MT]) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[u], f.x[i][u], acc[i], 0, 0, 0);
-}
-
-constexpr int SK_WAVES = 8;     // waves per workgroup = in-workgroup K split
-
-template <int MT>
-__global__ __launch_bounds__(64 * SK_WAVES) void gemm_bf16_skinny_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float red[SK_WAVES][MT][4][64];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int n0 = blockIdx.x * 16;
+// NCH = chunks per K slice (compile time, <= 4): the chunk loop is fully unrolled, EVERY weight load of the slice is in
+// flight before the first MFMA (NCH*CKS KiB per wave), and activation chunks are fetched two ahead.
+template <int MT, int CKS, int NCH>
+__global__ __launch_bounds__(256) void gemm_bf16_decode_kernel(GemmArgs g) {
+    constexpr int ROWB = CKS * 64 + 32;           // padded LDS row (bytes)
+    constexpr int CK = CKS * 32;                  // k per chunk
+    constexpr int CPR = CKS * 4;                  // 16-B pieces per activation row per chunk
+    constexpr int PIECES = MT * 16 * CPR;
+    constexpr int PPT = (PIECES + 255) / 256;     // pieces staged per thread
+    constexpr int BUF = MT * 16 * ROWB;
+    __shared__ __attribute__((aligned(16))) char lds[(NCH > 1 ? 2 : 1) * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int gq = lane >> 4, r = lane & 15;
-    const bf16* A = reinterpret_cast<const bf16*>(g.A);
+    const int ntiles = (g.N + DG_BN - 1) / DG_BN;
+    const int tile = blockIdx.x % ntiles, split = blockIdx.x / ntiles;
+    const int n0 = tile * DG_BN + wid * 16;
+    const int kbeg = split * (NCH * CK);
+
     int n = n0 + r; if (n > g.N - 1) n = g.N - 1;
-    const bf16* wp = reinterpret_cast<const bf16*>(g.W) + (int64_t)n * g.ldw + gq * 8;
-    const bf16* xp[MT];
+    const bf16* wp = reinterpret_cast<const bf16*>(g.W) + (int64_t)n * g.ldw + kbeg + gq * 8;
+    const bf16* xsrc[PPT];
+    int xdst[PPT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        int m = i * 16 + r; if (m > g.M - 1) m = g.M - 1;
-        xp[i] = A + a_row_offset(g, m) + gq * 8;
+    for (int j = 0; j < PPT; ++j) {
+        int p = tid + j * 256; if (p > PIECES - 1) p = PIECES - 1;     // duplicates write identical bytes
+        int row = p / CPR; const int c = p % CPR;
+        xdst[j] = row * ROWB + c * 16;
+        if (row > g.M - 1) row = g.M - 1;
+        xsrc[j] = reinterpret_cast<const bf16*>(g.A) + (int64_t)row * g.lda + kbeg + c * 8;
     }
+    bf16x8 xs[2][PPT], w[NCH][CKS];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) xs[0][j] = *reinterpret_cast<const bf16x8*>(xsrc[j]);
+    if constexpr (NCH > 1) {
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) xs[1][j] = *reinterpret_cast<const bf16x8*>(xsrc[j] + CK);
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int ks = 0; ks < CKS; ++ks) w[c][ks] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + c * CK + ks * 32));
     f32x4 acc[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int ngroups = g.K / 64;                       // launch_gemm guarantees K % 64 == 0
-    const int per = (ngroups + SK_WAVES - 1) / SK_WAVES;
-    const int wu = __builtin_amdgcn_readfirstlane(wid); // provably wave-uniform: scalar loop control
-    const int g0 = wu * per;                            // contiguous K slice per wave: full 128-B lines per row
-    int g1 = g0 + per; if (g1 > ngroups) g1 = ngroups;
-    // Batches of three 64-wide K groups: 30 loads (15 KB per wave) issued back to back, then their MFMAs behind
-    // counted waits.  Loads past the slice are clamped to a valid address and their result is not used, so no load
-    // sits under a branch (a conditional load makes hipcc drain vmcnt(0) per element).
-    for (int gi = g0; gi < g1; gi += 3) {
-        SkinnyFrag<MT> fa, fb, fc;
-        const int ga = gi, gb = gi + 1 < ngroups ? gi + 1 : ngroups - 1, gc = gi + 2 < ngroups ? gi + 2 : ngroups - 1;
-        skinny_load<MT>(fa, wp, xp, ga * 64);
-        skinny_load<MT>(fb, wp, xp, gb * 64);
-        skinny_load<MT>(fc, wp, xp, gc * 64);
-        __builtin_amdgcn_sched_barrier(0);   // keep all 30 loads in flight: hipcc otherwise sinks loads next to their MFMAs
-        skinny_mma<MT>(fa, acc);
-        if (gi + 1 < g1) skinny_mma<MT>(fb, acc);
-        if (gi + 2 < g1) skinny_mma<MT>(fc, acc);
-    }
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) red[wid][i][j][lane] = acc[i][j];
+    for (int j = 0; j < PPT; ++j) *reinterpret_cast<bf16x8*>(lds + xdst[j]) = xs[0][j];
     __syncthreads();
-    // wave w < MT finalises row tile w (fixed summation order over the K slices -> deterministic)
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        if (i == wid) {
-            f32x4 v;
+    for (int c = 0; c < NCH; ++c) {
+        if (c + 2 < NCH) {   // compile-time condition
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float t = red[0][i][j][lane];
+            for (int j = 0; j < PPT; ++j) xs[c & 1][j] = *reinterpret_cast<const bf16x8*>(xsrc[j] + (c + 2) * CK);
+        }
+        const char* buf = lds + (c & 1) * BUF;
 #pragma unroll
-                for (int w = 1; w < SK_WAVES; ++w) t += red[w][i][j][lane];
-                v[j] = t;
-            }
-            epilogue_store4(g.ep, i * 16 + r, n0 + gq * 4, v, g.M, g.N);
+        for (int ks = 0; ks < CKS; ++ks) {
+            bf16x8 xf[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(buf + (i * 16 + r) * ROWB + ks * 64 + gq * 16);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][ks], xf[i], acc[i], 0, 0, 0);
+        }
+        if (c + 1 < NCH) {
+            char* nb = lds + ((c + 1) & 1) * BUF;
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) *reinterpret_cast<bf16x8*>(nb + xdst[j]) = xs[(c + 1) & 1][j];
+            __syncthreads();
         }
     }
+    if (g.n_split == 1) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) epilogue_store4(g.ep, i * 16 + r, n0 + gq * 4, acc[i], g.M, g.N);
+    } else {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = i * 16 + r, nn = n0 + gq * 4;
+            if (m < g.M && nn < g.N) *reinterpret_cast<f32x4*>(g.partial + ((int64_t)split * g.M + m) * g.N + nn) = acc[i];
+        }
+    }
+}
+
+template <int MT, int CKS>
+static bool launch_decode_nch(const GemmArgs& g, int nch, int blocks, hipStream_t st) {
+    switch (nch) {
+        case 1: hipLaunchKernelGGL((gemm_bf16_decode_kernel<MT, CKS, 1>), dim3(blocks), dim3(256), 0, st, g); return true;
+        case 2: hipLaunchKernelGGL((gemm_bf16_decode_kernel<MT, CKS, 2>), dim3(blocks), dim3(256), 0, st, g); return true;
+        case 3: hipLaunchKernelGGL((gemm_bf16_decode_kernel<MT, CKS, 3>), dim3(blocks), dim3(256), 0, st, g); return true;
+        case 4: hipLaunchKernelGGL((gemm_bf16_decode_kernel<MT, CKS, 4>), dim3(blocks), dim3(256), 0, st, g); return true;
+        default: return false;
+    }
+}
+template <int MT>
+static bool launch_decode_mt(const GemmArgs& g, int cks, int nch, int blocks, hipStream_t st) {
+    switch (cks) {
+        case 10: return launch_decode_nch<MT, 10>(g, nch, blocks, st);
+        case 8: return launch_decode_nch<MT, 8>(g, nch, blocks, st);
+        case 4: return launch_decode_nch<MT, 4>(g, nch, blocks, st);
+        default: return false;
+    }
+}
+
+// k-steps (of 32) per LDS chunk for a K slice of kb; 0 = unsupported slice length
+static int decode_gemm_cks(int kb) {
+    if (kb % 320 == 0 && kb / 320 <= 4) return 10;
+    if (kb % 256 == 0 && kb / 256 <= 4) return 8;
+    if (kb % 128 == 0 && kb / 128 <= 4) return 4;
+    return 0;
+}
+
+// K-split that fills the chip for a decode GEMM whose consumer can add partial tiles (see above); 1 = no split.
+int decode_gemm_split(int N, int K) {
+    const int ntiles = (N + DG_BN - 1) / DG_BN;
+    int best = 1;
+    for (int s = 2; s <= 16; ++s) {
+        if (K % s) continue;
+        const int kb = K / s;
+        if (kb < 128 || !decode_gemm_cks(kb)) continue;
+        if (ntiles * s <= 256) best = s;
+    }
+    return best;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -331,16 +382,19 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
     if (g.ep.mode == 1 && (g.ep.hs_d % HEAD_DIM != 0 || g.ep.hs_T <= 0 || g.N % g.ep.hs_d != 0 || g.N / g.ep.hs_d > 3)) return -1;
     if (g.ep.colscale_period && (g.ep.colscale_period % 4 != 0 || (g.N + g.ep.colscale_period - 1) / g.ep.colscale_period > 3)) return -1;
     if (g.in_dtype == DT_BF16) {
-        if (g.M <= 64) {
-            if (g.K % 64 != 0) return -1;
-            const int blocks = (g.N + 15) / 16;
-            const int mt = (g.M + 15) / 16;
-            switch (mt) {
-                case 1: hipLaunchKernelGGL(gemm_bf16_skinny_kernel<1>, dim3(blocks), dim3(64 * SK_WAVES), 0, st, g); break;
-                case 2: hipLaunchKernelGGL(gemm_bf16_skinny_kernel<2>, dim3(blocks), dim3(64 * SK_WAVES), 0, st, g); break;
-                case 3: hipLaunchKernelGGL(gemm_bf16_skinny_kernel<3>, dim3(blocks), dim3(64 * SK_WAVES), 0, st, g); break;
-                default: hipLaunchKernelGGL(gemm_bf16_skinny_kernel<4>, dim3(blocks), dim3(64 * SK_WAVES), 0, st, g); break;
+        const int kb = (g.n_split >= 1 && g.K % g.n_split == 0) ? g.K / g.n_split : 0;
+        const int cks = kb ? decode_gemm_cks(kb) : 0;
+        if (g.n_split > 1 && (!cks || !g.partial || g.M > 64 || g.a_rows_per_batch != 0)) return -1;
+        if (g.M <= 64 && g.a_rows_per_batch == 0 && cks) {
+            const int blocks = ((g.N + DG_BN - 1) / DG_BN) * g.n_split, nch = kb / (cks * 32);
+            bool ok;
+            switch ((g.M + 15) / 16) {
+                case 1: ok = launch_decode_mt<1>(g, cks, nch, blocks, st); break;
+                case 2: ok = launch_decode_mt<2>(g, cks, nch, blocks, st); break;
+                case 3: ok = launch_decode_mt<3>(g, cks, nch, blocks, st); break;
+                default: ok = launch_decode_mt<4>(g, cks, nch, blocks, st); break;
             }
+            if (!ok) return -1;
         } else {
             if (g.K % TB_BK != 0) return -1;
             const int tiles = ((g.M + TB_BM - 1) / TB_BM) * ((g.N + TB_BN - 1) / TB_BN);
