@@ -93,5 +93,33 @@ int main(int argc, char** argv) {
         for (int S : {0, 1, 4, 5, 8, 10})
             printf("reduce+layernorm S=%2d   : %.2f us/launch\n", S, time_graph(st, 64, 20, [&] { for (int i = 0; i < 64; ++i) launch_reduce_layernorm(x, part, S, bt, gmm, bt, o, DT_BF16, M, d, st); }));
     }
+    {   // decoder self-attention (paged), B = M sequences x 20 heads, at several positions
+        const int H = 20, P = 28, B = M;
+        int32_t* pt; CK(hipMalloc(&pt, B * P * 4));
+        { std::vector<int32_t> h(B * P); for (int i = 0; i < B * P; ++i) h[i] = i; CK(hipMemcpy(pt, h.data(), h.size() * 4, hipMemcpyHostToDevice)); }
+        const size_t layer = (size_t)B * P * H * 16 * 64;
+        bf16 *kp, *vp; CK(hipMalloc(&kp, layer * L * 2)); CK(hipMalloc(&vp, layer * L * 2));
+        hipLaunchKernelGGL(fill_bf16, dim3(2048), dim3(256), 0, st, kp, layer * L, 1.0f);
+        hipLaunchKernelGGL(fill_bf16, dim3(2048), dim3(256), 0, st, vp, layer * L, 1.0f);
+        float* part; CK(hipMalloc(&part, (size_t)16 * 64 * 3 * d * 4)); CK(hipMemset(part, 0, (size_t)16 * 64 * 3 * d * 4));
+        float* bias; CK(hipMalloc(&bias, 3 * d * 4)); CK(hipMemset(bias, 0, 3 * d * 4));
+        bf16* qkv; CK(hipMalloc(&qkv, (size_t)64 * 3 * d * 2)); hipLaunchKernelGGL(fill_bf16, dim3(64), dim3(256), 0, st, qkv, (size_t)64 * 3 * d, 1.0f);
+        bf16* o; CK(hipMalloc(&o, 64 * d * 2));
+        int32_t* dpos; CK(hipMalloc(&dpos, 64));
+        for (int t : {8, 64, 224, 440}) for (int S : {0, 4}) {
+            CK(hipMemcpy(dpos, &t, 4, hipMemcpyHostToDevice));
+            const float us = time_graph(st, L, 20, [&] {
+                for (int l = 0; l < L; ++l) {
+                    AttnArgs a; a.dt = DT_BF16; a.n_q = 1; a.q_sb = 3 * d;
+                    if (S) { a.q_partial = part; a.q_bias = bias; a.q_nsplit = S; a.q_scale = 0.35f; }
+                    else { a.Q = qkv; a.Knew = qkv + d; a.Vnew = qkv + 2 * d; a.new_sb = 3 * d; }
+                    a.page_table = pt; a.pt_ld = P; a.Kpool = kp + layer * l; a.Vpool = vp + layer * l; a.d_pos = dpos;
+                    a.O = o; a.o_sb = d; a.B = B; a.H = H; a.n_split = 1;
+                    if (launch_attn_decode(a, st)) { printf("attn launch failed\n"); exit(1); }
+                }
+            });
+            printf("self-attn decode t=%3d partial S=%d: %6.2f us/launch (%.0f GB/s kv)\n", t, S, us, (double)B * H * (t + 1) * 256 / us * 1e-3);
+        }
+    }
     return 0;
 }

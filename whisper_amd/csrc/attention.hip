@@ -10,6 +10,7 @@
 // attn_rows    same lane mapping, NQ queries per wave sharing each K/V load: fp32 encoder attention ("token-exact"
 //              mode) and the reference implementation the MFMA flash kernel is tested against.
 #include "common.h"
+#include <cstdlib>
 
 namespace wx {
 
@@ -66,80 +67,176 @@ template <int E> __device__ __forceinline__ void merge_state(float& m, float& l,
 // ---------------------------------------------------------------------------------------------------------
 // decode: one query per (b, h)
 // ---------------------------------------------------------------------------------------------------------
-template <typename T, bool PAGED>
+// query (and, for self-attention, this step's key/value row) of head h of sequence b for lane `lane`: element `lane` of
+// each 64-wide row, either read directly or assembled from the projection GEMM's split-K partial tiles (fixed order,
+// all tiles in flight at once: loads past q_nsplit are clamped to the last tile and not added).
+template <typename T, int NROWS>
+__device__ __forceinline__ void load_head_rows(const AttnArgs& a, int b, int h, int lane, float (&out)[NROWS]) {
+    if (a.q_partial) {
+        const int dm = a.H * HEAD_DIM;
+#pragma unroll
+        for (int which = 0; which < NROWS; ++which) {
+            const int col = which * dm + h * HEAD_DIM + lane;
+            float pt[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) pt[s] = a.q_partial[((int64_t)(s < a.q_nsplit ? s : a.q_nsplit - 1) * a.B + b) * a.q_sb + col];
+            float v = a.q_bias[col];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) if (s < a.q_nsplit) v += pt[s];
+            if (which < 2) v *= a.q_scale;        // q and k carry head_dim^-0.25; v does not
+            out[which] = (float)(T)v;            // same rounding point as a stored q/k/v row
+        }
+    } else {
+        out[0] = (float)reinterpret_cast<const T*>(a.Q)[(int64_t)b * a.q_sb + h * a.q_sh + lane];
+        if (NROWS > 1) {
+            out[1] = (float)reinterpret_cast<const T*>(a.Knew)[(int64_t)b * a.new_sb + h * HEAD_DIM + lane];
+            out[2] = (float)reinterpret_cast<const T*>(a.Vnew)[(int64_t)b * a.new_sb + h * HEAD_DIM + lane];
+        }
+    }
+}
+
+// Decoder self-attention over the paged KV cache: NWH waves per (sequence, head) interleave the key iterations, four
+// heads per workgroup, so a batch-64 launch is 320 workgroups that are all resident at once.  Round trip 1 fetches
+// everything that depends on no other load (position, page-table row, q/k/v partial tiles); round trip 2 is the K/V
+// stream: <= 448 keys, 64 keys (8 KiB K + 8 KiB V in bf16) per iteration in flight per wave.
+template <typename T, int NWH>
+__global__ __launch_bounds__(256 * NWH) void attn_self_decode_kernel(AttnArgs a) {
+    typedef Chunk<T> C;
+    constexpr int EPL = C::EPL, LPK = HEAD_DIM / EPL, KPI = 64 / LPK, U = 8, IT = KPI * U;
+    __shared__ float s_row[4][3][HEAD_DIM];
+    __shared__ int s_pt[4][64];
+    __shared__ float s_m[4][NWH], s_l[4][NWH];
+    __shared__ float s_o[4][NWH][HEAD_DIM];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int hs = wid / NWH, kw = wid % NWH;          // head slot in the workgroup, key-split wave of that head
+    int bh = blockIdx.x * 4 + hs;
+    const bool valid = bh < a.B * a.H;
+    if (!valid) bh = a.B * a.H - 1;
+    const int b = bh / a.H, h = bh % a.H;
+    const int sub = lane % LPK, grp = lane / LPK;
+    const int t_cur = *a.d_pos, n_keys = t_cur + 1;
+    if (kw == 0) {
+        if (lane < a.pt_ld) s_pt[hs][lane] = a.page_table[b * a.pt_ld + lane];
+        float rows[3];
+        load_head_rows<T, 3>(a, b, h, lane, rows);
+#pragma unroll
+        for (int w = 0; w < 3; ++w) s_row[hs][w][lane] = rows[w];
+    }
+    __syncthreads();
+    float qf[EPL], kf[EPL], vf[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { qf[e] = s_row[hs][0][sub * EPL + e]; kf[e] = s_row[hs][1][sub * EPL + e]; vf[e] = s_row[hs][2][sub * EPL + e]; }
+    const typename C::Raw kn_r = C::pack(kf), vn_r = C::pack(vf);
+    T* Kp = reinterpret_cast<T*>(a.Kpool);
+    T* Vp = reinterpret_cast<T*>(a.Vpool);
+    if (valid && kw == 0 && lane < LPK) {     // append this step's key/value row to the page of position t_cur
+        const int64_t off = (((int64_t)s_pt[hs][t_cur / KV_PAGE] * a.H + h) * KV_PAGE + t_cur % KV_PAGE) * HEAD_DIM + sub * EPL;
+        *reinterpret_cast<typename C::Raw*>(Kp + off) = kn_r;
+        *reinterpret_cast<typename C::Raw*>(Vp + off) = vn_r;
+    }
+    float m = -INFINITY, l = 0.f, o[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) o[e] = 0.f;
+    const int total_it = (n_keys + IT - 1) / IT;
+    for (int it = kw; it < total_it; it += NWH) {
+        typename C::Raw kr[U], vr[U];
+        const int key0 = it * IT + grp;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int key = key0 + u * KPI;
+            if (key > n_keys - 1) key = n_keys - 1;
+            // the slot of position t_cur is being written by this launch: it is read (address valid, value ignored)
+            // and replaced by the register copy
+            const int64_t off = (((int64_t)s_pt[hs][key / KV_PAGE] * a.H + h) * KV_PAGE + key % KV_PAGE) * HEAD_DIM + sub * EPL;
+            kr[u] = __builtin_nontemporal_load(reinterpret_cast<const typename C::Raw*>(Kp + off));
+            vr[u] = __builtin_nontemporal_load(reinterpret_cast<const typename C::Raw*>(Vp + off));
+            if (key == t_cur) { kr[u] = kn_r; vr[u] = vn_r; }
+        }
+        float s[U];
+        float mt = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float kk[EPL];
+            C::unpack(kr[u], kk);
+            float d = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) d = fmaf(qf[e], kk[e], d);
+            d = group_sum<LPK>(d);
+            s[u] = (key0 + u * KPI < n_keys) ? d : -INFINITY;
+            mt = fmaxf(mt, s[u]);
+        }
+        if (mt > -INFINITY) {
+            const float mn = fmaxf(m, mt);
+            const float alpha = (m == -INFINITY) ? 0.f : exp2f((m - mn) * LOG2E);
+            l *= alpha;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) o[e] *= alpha;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float p = exp2f((s[u] - mn) * LOG2E);   // exp2(-inf) = 0 for masked keys
+                l += p;
+                float vv[EPL];
+                C::unpack(vr[u], vv);
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) o[e] = fmaf(p, vv[e], o[e]);
+            }
+            m = mn;
+        }
+    }
+#pragma unroll
+    for (int off = LPK; off < 64; off <<= 1) {
+        const float m2 = __shfl_xor(m, off), l2 = __shfl_xor(l, off);
+        float o2[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o2[e] = __shfl_xor(o[e], off);
+        merge_state<EPL>(m, l, o, m2, l2, o2);
+    }
+    if (lane < LPK) {
+        if (lane == 0) { s_m[hs][kw] = m; s_l[hs][kw] = l; }
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) s_o[hs][kw][sub * EPL + e] = o[e];
+    }
+    __syncthreads();
+    if (kw == 0 && valid) {
+        const int d = lane;
+        float M = s_m[hs][0];
+#pragma unroll
+        for (int w = 1; w < NWH; ++w) M = fmaxf(M, s_m[hs][w]);
+        float L = 0.f, acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWH; ++w) {
+            const float f = (s_m[hs][w] == -INFINITY) ? 0.f : exp2f((s_m[hs][w] - M) * LOG2E);
+            L += s_l[hs][w] * f;
+            acc += s_o[hs][w][d] * f;
+        }
+        reinterpret_cast<T*>(a.O)[(int64_t)b * a.o_sb + h * a.o_sh + d] = (T)(acc / L);
+    }
+}
+
+// Decoder cross-attention over the cached encoder K/V (dense [B][H][n_keys][64]): one workgroup per (b, h) and key split,
+// its four waves interleave the key iterations.
+template <typename T>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     typedef Chunk<T> C;
     constexpr int EPL = C::EPL, LPK = HEAD_DIM / EPL, KPI = 64 / LPK, U = 8, IT = KPI * U;
     __shared__ float s_m[4], s_l[4];
     __shared__ float s_o[4][HEAD_DIM];
+    __shared__ float s_q[HEAD_DIM];
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H, split = blockIdx.y;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int sub = lane % LPK, grp = lane / LPK;
-    const int t_cur = a.d_pos ? *a.d_pos : -1;
-    const int n_keys = a.d_pos ? t_cur + 1 : a.n_keys;
-
+    const int n_keys = a.n_keys;
+    if (wid == 0) {
+        float rows[1];
+        load_head_rows<T, 1>(a, b, h, lane, rows);
+        s_q[lane] = rows[0];
+    }
+    __syncthreads();
     float qf[EPL];
-    if (a.q_partial) {
-        // query = consumer-side reduction of its projection GEMM's split-K partial tiles (fixed order)
-        const int c0 = h * HEAD_DIM + sub * EPL;
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) qf[e] = a.q_bias[c0 + e];
-        for (int s = 0; s < a.q_nsplit; ++s) {
-            const float* pp = a.q_partial + ((int64_t)s * a.B + b) * a.q_sb + c0;
-#pragma unroll
-            for (int e = 0; e < EPL; e += 4) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(pp + e);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) qf[e + j] += t[j];
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) qf[e] = (float)(T)(qf[e] * a.q_scale);   // same rounding point as a stored query
-    } else {
-        const T* qp = reinterpret_cast<const T*>(a.Q) + (int64_t)b * a.q_sb + h * a.q_sh + sub * EPL;
-        C::unpack(*reinterpret_cast<const typename C::Raw*>(qp), qf);
-    }
-    const T* knew = nullptr; const T* vnew = nullptr;
-    typename C::Raw kn_r = {}, vn_r = {};       // this step's key/value chunk when it arrives as split-K partial tiles
-    const bool new_from_partial = PAGED && a.q_partial != nullptr;
-    if (PAGED) {
-        if (new_from_partial) {
-            // fused q|k|v projection: k at column d_model + h*64 (scaled like q, no bias), v at 2*d_model + h*64 (bias, unscaled)
-            const int dm = a.H * HEAD_DIM, c0 = h * HEAD_DIM + sub * EPL;
-            float kf[EPL], vf[EPL];
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) { kf[e] = a.q_bias[dm + c0 + e]; vf[e] = a.q_bias[2 * dm + c0 + e]; }
-            for (int s = 0; s < a.q_nsplit; ++s) {
-                const float* pp = a.q_partial + ((int64_t)s * a.B + b) * a.q_sb + c0;
-#pragma unroll
-                for (int e = 0; e < EPL; e += 4) {
-                    const f32x4 tk = *reinterpret_cast<const f32x4*>(pp + dm + e), tv = *reinterpret_cast<const f32x4*>(pp + 2 * dm + e);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { kf[e + j] += tk[j]; vf[e + j] += tv[j]; }
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) kf[e] *= a.q_scale;
-            kn_r = C::pack(kf); vn_r = C::pack(vf);
-        } else {
-            knew = reinterpret_cast<const T*>(a.Knew) + (int64_t)b * a.new_sb + h * HEAD_DIM + sub * EPL;
-            vnew = reinterpret_cast<const T*>(a.Vnew) + (int64_t)b * a.new_sb + h * HEAD_DIM + sub * EPL;
-            kn_r = *reinterpret_cast<const typename C::Raw*>(knew);
-            vn_r = *reinterpret_cast<const typename C::Raw*>(vnew);
-        }
-        if (split == 0 && wid == 0 && lane < LPK) {
-            // append this step's key/value row to the page of position t_cur
-            const int page = a.page_table[b * a.pt_ld + t_cur / KV_PAGE];
-            const int64_t off = (((int64_t)page * a.H + h) * KV_PAGE + t_cur % KV_PAGE) * HEAD_DIM + sub * EPL;
-            *reinterpret_cast<typename C::Raw*>(reinterpret_cast<T*>(a.Kpool) + off) = kn_r;
-            *reinterpret_cast<typename C::Raw*>(reinterpret_cast<T*>(a.Vpool) + off) = vn_r;
-        }
-    }
-    const T* kbase = nullptr; const T* vbase = nullptr;
-    if (!PAGED) {
-        kbase = reinterpret_cast<const T*>(a.K) + ((int64_t)b * a.H + h) * a.kv_sbh + sub * EPL;
-        vbase = reinterpret_cast<const T*>(a.V) + ((int64_t)b * a.H + h) * a.kv_sbh + sub * EPL;
-    }
+    for (int e = 0; e < EPL; ++e) qf[e] = s_q[sub * EPL + e];
+    const T* kbase = reinterpret_cast<const T*>(a.K) + ((int64_t)b * a.H + h) * a.kv_sbh + sub * EPL;
+    const T* vbase = reinterpret_cast<const T*>(a.V) + ((int64_t)b * a.H + h) * a.kv_sbh + sub * EPL;
     const int total_it = (n_keys + IT - 1) / IT;
     const int it0 = (int)((int64_t)split * total_it / a.n_split), it1 = (int)((int64_t)(split + 1) * total_it / a.n_split);
 
@@ -154,21 +251,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
         for (int u = 0; u < U; ++u) {
             int key = key0 + u * KPI;
             if (key > n_keys - 1) key = n_keys - 1;
-            const T* kp; const T* vp;
-            if (PAGED) {
-                // the row of position t_cur is being appended by this launch: its slot is read (address valid, value
-                // ignored) and replaced by the register copy below
-                const int page = a.page_table[b * a.pt_ld + key / KV_PAGE];
-                const int64_t off = (((int64_t)page * a.H + h) * KV_PAGE + key % KV_PAGE) * HEAD_DIM + sub * EPL;
-                kp = reinterpret_cast<const T*>(a.Kpool) + off;
-                vp = reinterpret_cast<const T*>(a.Vpool) + off;
-            } else {
-                kp = kbase + (int64_t)key * HEAD_DIM;
-                vp = vbase + (int64_t)key * HEAD_DIM;
-            }
-            kr[u] = __builtin_nontemporal_load(reinterpret_cast<const typename C::Raw*>(kp));
-            vr[u] = __builtin_nontemporal_load(reinterpret_cast<const typename C::Raw*>(vp));
-            if (PAGED && key == t_cur) { kr[u] = kn_r; vr[u] = vn_r; }
+            kr[u] = __builtin_nontemporal_load(reinterpret_cast<const typename C::Raw*>(kbase + (int64_t)key * HEAD_DIM));
+            vr[u] = __builtin_nontemporal_load(reinterpret_cast<const typename C::Raw*>(vbase + (int64_t)key * HEAD_DIM));
         }
         float s[U];
         float mt = -INFINITY;
@@ -358,7 +442,7 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnArgs a) {
 
 static int check_common(const AttnArgs& a) {
     if (a.B <= 0 || a.H <= 0 || (!a.Q && !a.q_partial) || !a.O) return -1;
-    if (a.q_partial && (!a.q_bias || a.q_nsplit < 1 || a.q_sb % 4 != 0)) return -1;
+    if (a.q_partial && (!a.q_bias || a.q_nsplit < 1 || a.q_nsplit > 16 || a.q_sb % 4 != 0)) return -1;
     const size_t es = dtype_size(a.dt);
     if ((a.q_sb * es) % 16 || (a.q_sq * es) % 16 || (a.q_sh * es) % 16 || (a.o_sb * es) % 16 || (a.o_sq * es) % 16 || (a.o_sh * es) % 16 || (a.kv_sbh * es) % 16 || (a.new_sb * es) % 16) return -1;
     return 0;
@@ -368,17 +452,25 @@ int launch_attn_decode(const AttnArgs& a, hipStream_t st) {
     if (check_common(a)) return -1;
     if (a.n_q != 1 || a.n_split < 1) return -1;
     const bool paged = a.page_table != nullptr;
-    if (paged && (!a.d_pos || !a.Kpool || !a.Vpool || (!a.q_partial && (!a.Knew || !a.Vnew)))) return -1;
-    if (!paged && (!a.K || !a.V || a.n_keys <= 0)) return -1;
+    if (paged) {
+        if (!a.d_pos || !a.Kpool || !a.Vpool || a.pt_ld > 64 || a.n_split != 1 || (!a.q_partial && (!a.Knew || !a.Vnew))) return -1;
+        static const int nwh = getenv("WX_SELF_NWH") ? atoi(getenv("WX_SELF_NWH")) : 2;
+        dim3 grid((a.B * a.H + 3) / 4);
+        if (a.dt == DT_BF16) {
+            if (nwh == 1) hipLaunchKernelGGL((attn_self_decode_kernel<bf16, 1>), grid, dim3(256), 0, st, a);
+            else if (nwh == 4) hipLaunchKernelGGL((attn_self_decode_kernel<bf16, 4>), grid, dim3(1024), 0, st, a);
+            else hipLaunchKernelGGL((attn_self_decode_kernel<bf16, 2>), grid, dim3(512), 0, st, a);
+        } else hipLaunchKernelGGL((attn_self_decode_kernel<float, 2>), grid, dim3(512), 0, st, a);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
+    if (!a.K || !a.V || a.n_keys <= 0) return -1;
     if (a.n_split > 1 && !a.partial) return -1;
     dim3 grid(a.B * a.H, a.n_split), block(256);
     if (a.dt == DT_BF16) {
-        if (paged) hipLaunchKernelGGL((attn_decode_kernel<bf16, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((attn_decode_kernel<bf16, false>), grid, block, 0, st, a);
+        hipLaunchKernelGGL(attn_decode_kernel<bf16>, grid, block, 0, st, a);
         if (a.n_split > 1) hipLaunchKernelGGL(attn_decode_combine_kernel<bf16>, dim3(a.B * a.H), dim3(64), 0, st, a);
     } else {
-        if (paged) hipLaunchKernelGGL((attn_decode_kernel<float, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((attn_decode_kernel<float, false>), grid, block, 0, st, a);
+        hipLaunchKernelGGL(attn_decode_kernel<float>, grid, block, 0, st, a);
         if (a.n_split > 1) hipLaunchKernelGGL(attn_decode_combine_kernel<float>, dim3(a.B * a.H), dim3(64), 0, st, a);
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;

@@ -75,6 +75,8 @@ int launch_layernorm(const float* x, const float* gamma, const float* beta, void
 // split-K decode GEMM whose epilogue is "residual add" (n_split == 0: plain LayerNorm, x untouched).
 int launch_reduce_layernorm(float* x, const float* partial, int n_split, const float* bias, const float* gamma,
                             const float* beta, void* out, int out_dtype, int rows, int d, hipStream_t st);
+// out[r][:] = bf16(gelu(bias + sum_s partial[s][r][:])): consumer side of a split-K decode GEMM with a GELU epilogue
+int launch_reduce_bias_gelu(const float* partial, int n_split, const float* bias, void* out_bf16, int rows, int N, hipStream_t st);
 // x[b][:] = tok_emb[tokens[b*ld_tok + *d_pos]][:] + pos_emb[*d_pos][:]   (fp32 out; embedding tables in `dt`)
 int launch_embed(const void* tok_emb, const void* pos_emb, int dt, const int32_t* tokens, int ld_tok,
                  const int32_t* d_pos, float* x, int B, int d, hipStream_t st);

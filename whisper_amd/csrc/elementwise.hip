@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void reduce_layernorm_kernel(float* __restrict
                                                                const float* __restrict__ bias, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, TO* __restrict__ out, int rows, int d) {
     constexpr int MAXV = 2;                       // d <= 256 * 4 * 2 = 2048
+    constexpr int MAX_SPLIT = 16;
     __shared__ float red[8];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, row = blockIdx.x;
     f32x4* xr = reinterpret_cast<f32x4*>(x + (int64_t)row * d);
@@ -95,8 +96,17 @@ __global__ __launch_bounds__(256) void reduce_layernorm_kernel(float* __restrict
         for (int i = 0; i < MAXV; ++i) {
             const int c = tid + i * 256;
             if (c < nv) {
-                f32x4 t = reinterpret_cast<const f32x4*>(partial + (int64_t)row * d)[c];
-                for (int s = 1; s < n_split; ++s) t += reinterpret_cast<const f32x4*>(partial + ((int64_t)s * rows + row) * d)[c];
+                // all partial tiles in flight at once: a runtime-bounded loop would serialise n_split round trips.
+                // Loads past n_split are clamped to the last tile and not added (no load under a branch).
+                f32x4 pt[MAX_SPLIT];
+#pragma unroll
+                for (int s = 0; s < MAX_SPLIT; ++s) {
+                    const int sc = s < n_split ? s : n_split - 1;
+                    pt[s] = reinterpret_cast<const f32x4*>(partial + ((int64_t)sc * rows + row) * d)[c];
+                }
+                f32x4 t = pt[0];
+#pragma unroll
+                for (int s = 1; s < MAX_SPLIT; ++s) if (s < n_split) t += pt[s];
                 v[i] += t + br[c];
                 xr[c] = v[i];
             }
@@ -148,10 +158,38 @@ __global__ __launch_bounds__(256) void reduce_layernorm_kernel(float* __restrict
 
 int launch_reduce_layernorm(float* x, const float* partial, int n_split, const float* bias, const float* gamma, const float* beta,
                             void* out, int out_dtype, int rows, int d, hipStream_t st) {
-    if (d % 4 != 0 || d > 2048 || rows <= 0 || n_split < 0 || (n_split > 0 && (!partial || !bias))) return -1;
+    if (d % 4 != 0 || d > 2048 || rows <= 0 || n_split < 0 || n_split > 16 || (n_split > 0 && (!partial || !bias))) return -1;
     const int blocks = rows;
     if (out_dtype == DT_F32) hipLaunchKernelGGL(reduce_layernorm_kernel<float>, dim3(blocks), dim3(256), 0, st, x, partial, n_split, bias, gamma, beta, (float*)out, rows, d);
     else hipLaunchKernelGGL(reduce_layernorm_kernel<bf16>, dim3(blocks), dim3(256), 0, st, x, partial, n_split, bias, gamma, beta, (bf16*)out, rows, d);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// Consumer side of a split-K decode GEMM with a GELU epilogue (the MLP's first projection):
+// out = bf16(gelu(bias + sum_s partial[s])), fixed summation order.  Pure streaming, 16 B per lane, whole chip.
+__global__ __launch_bounds__(256) void reduce_bias_gelu_kernel(const float* __restrict__ partial, int n_split, int64_t split_stride,
+                                                               const float* __restrict__ bias, bf16* __restrict__ out, int64_t total4, int N) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    f32x4 pt[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) pt[s] = reinterpret_cast<const f32x4*>(partial + (s < n_split ? s : n_split - 1) * split_stride)[i];
+    f32x4 v = pt[0];
+#pragma unroll
+    for (int s = 1; s < 4; ++s) if (s < n_split) v += pt[s];
+    for (int s = 4; s < n_split; ++s) v += reinterpret_cast<const f32x4*>(partial + s * split_stride)[i];
+    v += *reinterpret_cast<const f32x4*>(bias + (i * 4) % N);
+    bf16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (bf16)(0.5f * v[j] * (1.0f + erff(v[j] * 0.70710678118654752440f)));
+    reinterpret_cast<bf16x4*>(out)[i] = o;
+}
+
+int launch_reduce_bias_gelu(const float* partial, int n_split, const float* bias, void* out_bf16, int rows, int N, hipStream_t st) {
+    if (rows <= 0 || N % 4 != 0 || n_split < 1 || !partial || !bias || !out_bf16) return -1;
+    const int64_t total4 = (int64_t)rows * N / 4;
+    hipLaunchKernelGGL(reduce_bias_gelu_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, partial, n_split,
+                       (int64_t)rows * N, bias, (bf16*)out_bf16, total4, N);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -272,9 +310,34 @@ __device__ __forceinline__ float wave_max(float x) {
     return x;
 }
 
-__global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs s) {
-    __shared__ MaxIdx sh_all[4], sh_ts[4];
-    __shared__ float sh_f[4], sh_g[4];
+// online (max, sum exp) pair
+struct MS { float m, s; };
+__device__ __forceinline__ void ms_add(MS& a, float v) {
+    if (v > a.m) { a.s = a.s * expf(a.m - v) + 1.f; a.m = v; } else a.s += expf(v - a.m);
+}
+__device__ __forceinline__ MS ms_merge(MS a, MS b) {
+    if (b.m == -INFINITY) return a;
+    if (a.m == -INFINITY) return b;
+    const float m = fmaxf(a.m, b.m);
+    return MS{m, a.s * expf(a.m - m) + b.s * expf(b.m - m)};
+}
+__device__ __forceinline__ MS wave_ms(MS x) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        MS y; y.m = __shfl_xor(x.m, off); y.s = __shfl_xor(x.s, off);
+        x = ms_merge(x, y);
+    }
+    return x;
+}
+
+constexpr int SAMP_NT = 1024, SAMP_NW = SAMP_NT / 64;
+
+// One workgroup of 16 waves per sequence; ONE pass over the 200 KB logit row (16-B loads, suppress mask read 4 bytes at a
+// time, online max / sum-exp), because a CU sustains only ~25 GB/s of loads and a second pass would double the time.
+__global__ __launch_bounds__(SAMP_NT) void sampler_kernel(SamplerArgs s) {
+    __shared__ MaxIdx sh_all[SAMP_NW], sh_ts[SAMP_NW];
+    __shared__ MS sh_msa[SAMP_NW], sh_mst[SAMP_NW];
+    __shared__ float sh_f[SAMP_NW], sh_g[SAMP_NW];
     __shared__ int sh_flags[8];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int t = *s.d_pos;
@@ -283,17 +346,22 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs s) {
 
     if (t == s.sot_index && s.no_speech) {
         float mx = -INFINITY;
-        for (int i = tid; i < V; i += 256) mx = fmaxf(mx, lg[i]);
+        for (int i = tid; i < V; i += SAMP_NT) mx = fmaxf(mx, lg[i]);
         mx = wave_max(mx);
         if (lane == 0) sh_f[wid] = mx;
         __syncthreads();
-        mx = fmaxf(fmaxf(sh_f[0], sh_f[1]), fmaxf(sh_f[2], sh_f[3]));
+        mx = sh_f[0];
+        for (int w = 1; w < SAMP_NW; ++w) mx = fmaxf(mx, sh_f[w]);
         float se = 0.f;
-        for (int i = tid; i < V; i += 256) se += expf(lg[i] - mx);
+        for (int i = tid; i < V; i += SAMP_NT) se += expf(lg[i] - mx);
         se = wave_sum(se);
         if (lane == 0) sh_g[wid] = se;
         __syncthreads();
-        if (tid == 0) s.no_speech[b] = expf(lg[s.tok_no_speech] - mx) / ((sh_g[0] + sh_g[1]) + (sh_g[2] + sh_g[3]));
+        if (tid == 0) {
+            float tot = 0.f;
+            for (int w = 0; w < SAMP_NW; ++w) tot += sh_g[w];
+            s.no_speech[b] = expf(lg[s.tok_no_speech] - mx) / tot;
+        }
         __syncthreads();
     }
 
@@ -324,52 +392,51 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs s) {
         __syncthreads();
         const int a_lo = sh_flags[0], a_hi = sh_flags[1], b_lo = sh_flags[2], b_hi = sh_flags[3], c_hi = sh_flags[4], d_lo = sh_flags[5];
         const bool ts_mode = !s.without_timestamps;
-        auto masked = [&](int i) -> bool {
-            if (s.suppress[i]) return true;
-            if (first_step && s.suppress_blank && (i == s.tok_blank || i == s.tok_eot)) return true;
-            if (ts_mode) {
-                if (i == s.tok_no_timestamps) return true;
-                if (i >= a_lo && i < a_hi) return true;
-                if (i >= b_lo && i < b_hi) return true;
-                if (i < c_hi || i >= d_lo) return true;
-            }
-            return false;
-        };
+        const bool blank_rule = first_step && s.suppress_blank;
         MaxIdx best_all{-INFINITY, 0x7fffffff}, best_ts{-INFINITY, 0x7fffffff};
+        MS ms_all{-INFINITY, 0.f}, ms_ts{-INFINITY, 0.f};
         float max_text = -INFINITY;
-        for (int i = tid; i < V; i += 256) {
-            if (masked(i)) continue;
-            const float v = lg[i];
-            best_all = better(best_all, MaxIdx{v, i});
-            if (i >= tb) best_ts = better(best_ts, MaxIdx{v, i}); else max_text = fmaxf(max_text, v);
+        // suppress[] is padded to a multiple of 4 bytes (wx_finalize), logits rows to 16 floats
+        for (int i0 = tid * 4; i0 < V; i0 += SAMP_NT * 4) {
+            const f32x4 v4 = *reinterpret_cast<const f32x4*>(lg + i0);
+            const uint32_t sup = *reinterpret_cast<const uint32_t*>(s.suppress + i0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + j;
+                bool m = i >= V || ((sup >> (8 * j)) & 0xff);
+                if (blank_rule && (i == s.tok_blank || i == s.tok_eot)) m = true;
+                if (ts_mode) {
+                    if (i == s.tok_no_timestamps) m = true;
+                    if (i >= a_lo && i < a_hi) m = true;
+                    if (i >= b_lo && i < b_hi) m = true;
+                    if (i < c_hi || i >= d_lo) m = true;
+                }
+                if (m) continue;
+                const float v = v4[j];
+                best_all = better(best_all, MaxIdx{v, i});
+                ms_add(ms_all, v);
+                if (i >= tb) { best_ts = better(best_ts, MaxIdx{v, i}); if (ts_mode) ms_add(ms_ts, v); }
+                else max_text = fmaxf(max_text, v);
+            }
         }
         best_all = wave_best(best_all); best_ts = wave_best(best_ts); max_text = wave_max(max_text);
-        if (lane == 0) { sh_all[wid] = best_all; sh_ts[wid] = best_ts; sh_f[wid] = max_text; }
-        __syncthreads();
-        best_all = better(better(sh_all[0], sh_all[1]), better(sh_all[2], sh_all[3]));
-        best_ts = better(better(sh_ts[0], sh_ts[1]), better(sh_ts[2], sh_ts[3]));
-        max_text = fmaxf(fmaxf(sh_f[0], sh_f[1]), fmaxf(sh_f[2], sh_f[3]));
-        __syncthreads();
-        float sum_all = 0.f, sum_ts = 0.f;
-        for (int i = tid; i < V; i += 256) {
-            if (masked(i)) continue;
-            const float v = lg[i];
-            sum_all += expf(v - best_all.v);
-            if (i >= tb && ts_mode) sum_ts += expf(v - best_ts.v);
-        }
-        sum_all = wave_sum(sum_all); sum_ts = wave_sum(sum_ts);
-        if (lane == 0) { sh_f[wid] = sum_all; sh_g[wid] = sum_ts; }
+        ms_all = wave_ms(ms_all); ms_ts = wave_ms(ms_ts);
+        if (lane == 0) { sh_all[wid] = best_all; sh_ts[wid] = best_ts; sh_f[wid] = max_text; sh_msa[wid] = ms_all; sh_mst[wid] = ms_ts; }
         __syncthreads();
         if (tid == 0) {
-            sum_all = (sh_f[0] + sh_f[1]) + (sh_f[2] + sh_f[3]);
-            sum_ts = (sh_g[0] + sh_g[1]) + (sh_g[2] + sh_g[3]);
+            for (int w = 1; w < SAMP_NW; ++w) {
+                best_all = better(best_all, sh_all[w]); best_ts = better(best_ts, sh_ts[w]);
+                max_text = fmaxf(max_text, sh_f[w]);
+                ms_all = ms_merge(ms_all, sh_msa[w]); ms_ts = ms_merge(ms_ts, sh_mst[w]);
+            }
+            // ms_*.m equals best_*.v (both are the maximum of the same set), so sum exp(v - max) = ms_*.s
             int chosen = best_all.i;
-            float logprob = -logf(sum_all);
+            float logprob = -logf(ms_all.s);
             if (ts_mode && best_ts.v > -INFINITY) {
-                const float lse_all = best_all.v + logf(sum_all);
-                const float ts_lp = best_ts.v + logf(sum_ts) - lse_all;
+                const float lse_all = best_all.v + logf(ms_all.s);
+                const float ts_lp = best_ts.v + logf(ms_ts.s) - lse_all;
                 const float text_lp = max_text - lse_all;
-                if (ts_lp > text_lp) { chosen = best_ts.i; logprob = -logf(sum_ts); }
+                if (ts_lp > text_lp) { chosen = best_ts.i; logprob = -logf(ms_ts.s); }
             }
             const bool alive = row[t] != s.tok_eot;
             if (alive) s.sum_logprob[b] += logprob;
@@ -387,7 +454,7 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs s) {
 
 int launch_sampler(const SamplerArgs& s, hipStream_t st) {
     if (s.B <= 0 || !s.logits || !s.tokens || !s.d_pos || !s.d_block_counter || !s.suppress) return -1;
-    hipLaunchKernelGGL(sampler_kernel, dim3(s.B), dim3(256), 0, st, s);
+    hipLaunchKernelGGL(sampler_kernel, dim3(s.B), dim3(SAMP_NT), 0, st, s);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

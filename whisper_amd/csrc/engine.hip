@@ -380,7 +380,7 @@ int wx_finalize(wx_engine* e) {
         e->mel.window = w; e->mel.cs = t; e->mel.filters = f; e->mel.frange = (const int32_t*)fp; e->mel.n_mels = c.n_mels;
     }
     {
-        std::vector<uint8_t> m(c.n_vocab, 0);
+        std::vector<uint8_t> m(e->vocab_pad, 0);       // padded: the sampler reads the mask 4 bytes at a time
         for (int id : e->suppress_h) m[id] = 1;
         void* p;
         if ((r = dev_alloc(e, &p, m.size(), true))) return r;
@@ -629,74 +629,87 @@ static int decode_step_f32(wx_engine* e, int B, const SamplerArgs& sa, hipStream
     return 0;
 }
 
-// bf16 sequence (B <= 64): the three residual GEMMs of a layer and the cross-attention query projection split K over
-// workgroups and hand raw fp32 partial tiles to their consumer -- the next LayerNorm (reduce + bias + residual + LN in
-// one kernel) or the cross-attention kernel's query load -- so every weight byte streams once with the whole chip
-// pulling, and no launch is added.  11 launches per layer.
-static int decode_step_bf16(wx_engine* e, int B, const SamplerArgs& sa, hipStream_t st) {
+// bf16 sequence (rows [b0, b0 + B) of the batch, B <= 64): the q|k|v projection, the three residual GEMMs of a layer and
+// the cross-attention query projection split K over workgroups and hand raw fp32 partial tiles to their consumer -- the
+// next LayerNorm (reduce + bias + residual + LN in one kernel) or the attention kernel's q/k/v load -- so every weight
+// byte streams once with the whole chip pulling, and no launch is added.  11 launches per layer.
+static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, float* apartial, bool prof_ok, hipStream_t st) {
     const int d = e->d, dtp = e->dt, T = e->T;
     const size_t es = dtype_size(dtp);
     const wx_config& c = e->cfg;
-    WX_TRY(launch_embed(e->tok_emb, e->dec_pos, dtp, e->tokens, c.n_text_ctx, e->d_pos, e->dx, B, d, st));
-    const size_t cross_layer = (size_t)c.max_batch * e->Ht * T * HEAD_DIM;
+    float* dx = e->dx + (size_t)b0 * d;
+    char* dxn = (char*)e->dxn + (size_t)b0 * d * es;
+    char* datt = (char*)e->datt + (size_t)b0 * d * es;
+    char* dhid = (char*)e->dhid + (size_t)b0 * 4 * d * es;
+    WX_TRY(launch_embed(e->tok_emb, e->dec_pos, dtp, e->tokens + (size_t)b0 * c.n_text_ctx, c.n_text_ctx, e->d_pos, dx, B, d, st));
+    const size_t cross_layer = (size_t)c.max_batch * e->Ht * T * HEAD_DIM, cross_b0 = (size_t)b0 * e->Ht * T * HEAD_DIM;
     const size_t self_layer = (size_t)c.max_batch * e->n_pages_seq * e->Ht * KV_PAGE * HEAD_DIM;
     int n_split = 1;
     while (n_split < 6 && B * e->Ht * n_split < 512) ++n_split;
-    const int s_dd = decode_gemm_split(d, d), s_fc2 = decode_gemm_split(d, 4 * d), s_qkv = decode_gemm_split(3 * d, d);
+    const int s_dd = decode_gemm_split(d, d), s_fc2 = decode_gemm_split(d, 4 * d), s_qkv = decode_gemm_split(3 * d, d),
+              s_fc1 = decode_gemm_split(4 * d, d);
     int pend_split = 0; const float* pend_bias = nullptr;       // residual update not yet folded into dx
     auto split_gemm = [&](const void* A, int64_t lda, const void* W, int K, int S) {
         GemmArgs g = gemm_basic(e, A, lda, W, B, d, K);
-        g.n_split = S; g.partial = e->gpartial;
-        if (S == 1) { g.ep.out = e->gpartial; g.ep.out_dtype = DT_F32; g.ep.ldo = d; }   // one "partial": same consumer path
+        g.n_split = S; g.partial = gpartial;
+        if (S == 1) { g.ep.out = gpartial; g.ep.out_dtype = DT_F32; g.ep.ldo = d; }   // one "partial": same consumer path
         return launch_gemm(g, st);
     };
     for (int i = 0; i < c.n_text_layer; ++i) {
         const LayerW& L = e->dec[i];
-        WX_TRY(launch_reduce_layernorm(e->dx, e->gpartial, pend_split, pend_bias, L.ln1_g, L.ln1_b, e->dxn, dtp, B, d, st));
+        WX_TRY(launch_reduce_layernorm(dx, gpartial, pend_split, pend_bias, L.ln1_g, L.ln1_b, dxn, dtp, B, d, st));
         {   // fused q|k|v projection, split K: the self-attention kernel adds the partial tiles, bias and scale itself
-            GemmArgs g = gemm_basic(e, e->dxn, d, L.self.wqkv, B, 3 * d, d);
-            g.n_split = s_qkv; g.partial = e->gpartial;
-            if (s_qkv == 1) { g.ep.out = e->gpartial; g.ep.out_dtype = DT_F32; g.ep.ldo = 3 * d; }
+            GemmArgs g = gemm_basic(e, dxn, d, L.self.wqkv, B, 3 * d, d);
+            g.n_split = s_qkv; g.partial = gpartial;
+            if (s_qkv == 1) { g.ep.out = gpartial; g.ep.out_dtype = DT_F32; g.ep.ldo = 3 * d; }
             WX_TRY(launch_gemm(g, st));
         }
         {
             AttnArgs a;
-            a.dt = dtp; a.q_partial = e->gpartial; a.q_bias = L.self.bqkv; a.q_nsplit = s_qkv; a.q_scale = e->qk_scale; a.q_sb = 3 * d; a.n_q = 1;
-            a.page_table = e->page_table; a.pt_ld = e->n_pages_seq;
+            a.dt = dtp; a.q_partial = gpartial; a.q_bias = L.self.bqkv; a.q_nsplit = s_qkv; a.q_scale = e->qk_scale; a.q_sb = 3 * d; a.n_q = 1;
+            a.page_table = e->page_table + (size_t)b0 * e->n_pages_seq; a.pt_ld = e->n_pages_seq;
             a.Kpool = (char*)e->selfK + self_layer * i * es; a.Vpool = (char*)e->selfV + self_layer * i * es;
-            a.d_pos = e->d_pos; a.O = e->datt; a.o_sb = d; a.B = B; a.H = e->Ht; a.n_split = 1;
+            a.d_pos = e->d_pos; a.O = datt; a.o_sb = d; a.B = B; a.H = e->Ht; a.n_split = 1;
             WX_TRY(launch_attn_decode(a, st));
         }
-        WX_TRY(split_gemm(e->datt, d, L.self.wo, d, s_dd));
-        WX_TRY(launch_reduce_layernorm(e->dx, e->gpartial, s_dd, L.self.bo, L.lnx_g, L.lnx_b, e->dxn, dtp, B, d, st));
-        WX_TRY(split_gemm(e->dxn, d, L.xq, d, s_dd));
+        WX_TRY(split_gemm(datt, d, L.self.wo, d, s_dd));
+        WX_TRY(launch_reduce_layernorm(dx, gpartial, s_dd, L.self.bo, L.lnx_g, L.lnx_b, dxn, dtp, B, d, st));
+        WX_TRY(split_gemm(dxn, d, L.xq, d, s_dd));
         {
             AttnArgs a;
-            a.dt = dtp; a.q_partial = e->gpartial; a.q_bias = L.xbq; a.q_nsplit = s_dd; a.q_scale = e->qk_scale; a.q_sb = d; a.n_q = 1;
-            a.K = (char*)e->crossK + cross_layer * i * es; a.V = (char*)e->crossV + cross_layer * i * es;
+            a.dt = dtp; a.q_partial = gpartial; a.q_bias = L.xbq; a.q_nsplit = s_dd; a.q_scale = e->qk_scale; a.q_sb = d; a.n_q = 1;
+            a.K = (char*)e->crossK + (cross_layer * i + cross_b0) * es; a.V = (char*)e->crossV + (cross_layer * i + cross_b0) * es;
             a.kv_sbh = (int64_t)T * HEAD_DIM; a.n_keys = T;
-            a.O = e->datt; a.o_sb = d; a.B = B; a.H = e->Ht; a.n_split = n_split; a.partial = e->partial;
-            const bool prof = e->prof_on && e->prof_used + 2 <= e->prof_events.size();
+            a.O = datt; a.o_sb = d; a.B = B; a.H = e->Ht; a.n_split = n_split; a.partial = apartial;
+            const bool prof = prof_ok && e->prof_on && e->prof_used + 2 <= e->prof_events.size();
             if (prof) HIP_TRY(hipEventRecord(e->prof_events[e->prof_used], st));
             WX_TRY(launch_attn_decode(a, st));
             if (prof) { HIP_TRY(hipEventRecord(e->prof_events[e->prof_used + 1], st)); e->prof_used += 2; }
         }
-        WX_TRY(split_gemm(e->datt, d, L.xo, d, s_dd));
-        WX_TRY(launch_reduce_layernorm(e->dx, e->gpartial, s_dd, L.xbo, L.ln2_g, L.ln2_b, e->dxn, dtp, B, d, st));
+        WX_TRY(split_gemm(datt, d, L.xo, d, s_dd));
+        WX_TRY(launch_reduce_layernorm(dx, gpartial, s_dd, L.xbo, L.ln2_g, L.ln2_b, dxn, dtp, B, d, st));
         {
-            GemmArgs g = gemm_basic(e, e->dxn, d, L.w1, B, 4 * d, d);
-            g.ep.bias = L.b1; g.ep.act = 1; g.ep.out = e->dhid; g.ep.out_dtype = dtp; g.ep.ldo = 4 * d;
+            GemmArgs g = gemm_basic(e, dxn, d, L.w1, B, 4 * d, d);
+            if (s_fc1 > 1) { g.n_split = s_fc1; g.partial = gpartial; }
+            else { g.ep.bias = L.b1; g.ep.act = 1; g.ep.out = dhid; g.ep.out_dtype = dtp; g.ep.ldo = 4 * d; }
             WX_TRY(launch_gemm(g, st));
+            if (s_fc1 > 1) WX_TRY(launch_reduce_bias_gelu(gpartial, s_fc1, L.b1, dhid, B, 4 * d, st));
         }
-        WX_TRY(split_gemm(e->dhid, 4 * d, L.w2, 4 * d, s_fc2));
+        WX_TRY(split_gemm(dhid, 4 * d, L.w2, 4 * d, s_fc2));
         pend_split = s_fc2; pend_bias = L.b2;
     }
-    WX_TRY(launch_reduce_layernorm(e->dx, e->gpartial, pend_split, pend_bias, e->declnf_g, e->declnf_b, e->dxn, dtp, B, d, st));
+    WX_TRY(launch_reduce_layernorm(dx, gpartial, pend_split, pend_bias, e->declnf_g, e->declnf_b, dxn, dtp, B, d, st));
     {
-        GemmArgs g = gemm_basic(e, e->dxn, d, e->tok_emb, B, e->vocab_pad, d);
-        g.ep.out = e->logits; g.ep.out_dtype = DT_F32; g.ep.ldo = e->vocab_pad;
+        GemmArgs g = gemm_basic(e, dxn, d, e->tok_emb, B, e->vocab_pad, d);
+        g.ep.out = e->logits + (size_t)b0 * e->vocab_pad; g.ep.out_dtype = DT_F32; g.ep.ldo = e->vocab_pad;
         WX_TRY(launch_gemm(g, st));
     }
+    return 0;
+}
+
+static int decode_step_bf16(wx_engine* e, int B, const SamplerArgs& sa, hipStream_t st) {
+    int r = decode_layers_bf16(e, 0, B, e->gpartial, e->partial, true, st);
+    if (r) return r;
     WX_TRY(launch_sampler(sa, st));
     return 0;
 }
@@ -747,19 +760,25 @@ int wx_decode_greedy(wx_engine* e, int32_t B, const int32_t* h_prompt, const wx_
     const SamplerArgs sa = make_sampler(e, B, o, 0);
     const int total_steps = o.n_prompt - 1 + sample_len;   // positions 0 .. n_prompt-2 feed the prompt, then sample_len sampling steps
     hipGraphExec_t exec = nullptr;
+    auto capture = [&](hipStream_t cs, auto&& body, hipGraphExec_t* out) -> int {
+        hipGraph_t graph = nullptr;
+        HIP_TRY(hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
+        int r = body();
+        hipError_t ce = hipStreamEndCapture(cs, &graph);
+        if (r != 0) { if (graph) (void)hipGraphDestroy(graph); return r; }
+        if (ce != hipSuccess) return fail(WX_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+        hipError_t ie = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ie != hipSuccess) { *out = nullptr; return fail(WX_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
+        return 0;
+    };
     if (o.use_graph) {
         std::vector<int> key = {B, o.n_prompt, o.sot_index, o.without_timestamps, o.suppress_blank, o.max_initial_timestamp_index};
         if (!e->graph_exec || e->graph_key != key) {
             if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
-            hipGraph_t graph = nullptr;
-            HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
-            int r = decode_step(e, B, sa, st);
-            hipError_t ce = hipStreamEndCapture(st, &graph);
-            if (r != 0) { if (graph) (void)hipGraphDestroy(graph); return r; }
-            if (ce != hipSuccess) return fail(WX_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
-            hipError_t ie = hipGraphInstantiate(&e->graph_exec, graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
-            if (ie != hipSuccess) { e->graph_exec = nullptr; return fail(WX_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
+            e->graph_key.clear();
+            int r = capture(st, [&] { return decode_step(e, B, sa, st); }, &e->graph_exec);
+            if (r) return r;
             e->graph_key = key;
         }
         exec = e->graph_exec;
