@@ -107,6 +107,23 @@ def test_encoder_and_logits_parity(models, name, precision, gain):
     check_close(lg, ref, precision, sharp=gain > 1.0)
 
 
+def test_encoder_parity_256_tiles_bf16(models):
+    """3 windows of a 256-wide model: M = 4500 rows (a ragged last tile) takes the 256x256 LDS-DMA GEMM kernel; the decoder
+    runs its split-K GEMMs at K = 256 / 1024."""
+    dims, sd, eng = models("micro256", "bf16", attn_gain=1.0)
+    om = wo.OracleWhisper(dims, sd)
+    mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(s), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000] for s in (0, 1, 2)])
+    with torch.no_grad():
+        xa = om.encode(mels)
+    eng.encode_windows(mels)
+    check_close(eng.encoder_output(3).cpu(), xa, "bf16", sharp=False)
+    tok = eng.tok
+    toks = torch.tensor([[tok.sot, tok.lang(0), tok.transcribe, tok.no_timestamps, 100, 2000, 31337]] * 3)
+    with torch.no_grad():
+        ref = om.logits(toks, xa)
+    check_close(eng.decoder_logits(toks).cpu(), ref, "bf16", sharp=False)
+
+
 @pytest.mark.parametrize("name", ["micro", "tiny"])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_greedy_tokens_bit_exact_fp32(models, name, use_graph):

@@ -51,6 +51,8 @@ _NAMED = {
     # not an upstream model: a 2-layer, 2-head model with the real context sizes, for fast tests
     "micro": dict(d=128, h=2, le=2, ld=2, mels=80, vocab=51865),
     "micro128": dict(d=128, h=2, le=1, ld=1, mels=128, vocab=51866),
+    # not an upstream model: widths that are multiples of 256, so a 3-window batch reaches the 256x256 encoder GEMM tiles
+    "micro256": dict(d=256, h=4, le=2, ld=2, mels=80, vocab=51865),
 }
 _ALIASES = {"large": "large-v3", "turbo": "large-v3-turbo"}
 

@@ -9,6 +9,8 @@
 // The MFMA operands are swapped (W is the A operand, the activation the B operand) so each lane ends up with 4
 // CONSECUTIVE output columns of one row: bias/GELU/residual/positional adds and the stores are 8/16-byte vectors.
 #include "common.h"
+#include <cstdlib>
+#include <type_traits>
 
 namespace wx {
 
@@ -66,14 +68,19 @@ __device__ __forceinline__ int64_t a_row_offset(const GemmArgs& g, int m) {
     return (int64_t)m * g.lda;
 }
 
-// Blocks that share an XCD (blockIdx % 8) get a contiguous run of tiles, n fastest, so an XCD's L2 sees each
-// activation row-panel once and keeps the (small) weight panel resident.  Bijective for any tile count.
+// Blocks that share an XCD (blockIdx % 8) get a contiguous run of tiles, and inside the run tiles are ordered in bands of
+// GM row-tiles with m fastest, so the ~64-128 tiles an XCD runs at once form a squarish GM x (concurrency / GM) patch
+// that shares GM activation panels and a dozen weight panels through that XCD's 4 MiB L2 (n-fastest order made every
+// patch sweep the whole weight matrix: 5-10 GB of L2 misses per encoder GEMM).  Bijective for any tile count.
+template <int GM = 8>
 __device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int& tm, int& tn) {
     const int nwg = tiles_m * tiles_n, orig = blockIdx.x;
     const int q = nwg / 8, r = nwg % 8, xcd = orig % 8;
     const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
-    tm = lin / tiles_n;
-    tn = lin % tiles_n;
+    const int band = lin / (GM * tiles_n), in_band = lin % (GM * tiles_n);
+    const int rows = min(GM, tiles_m - band * GM);          // the last band may be shorter
+    tm = band * GM + in_band % rows;
+    tn = in_band / rows;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_tile_kernel(GemmArgs g) {
     char* ldsW = lds + TB_BM * 128;
     const int tiles_m = (g.M + TB_BM - 1) / TB_BM, tiles_n = (g.N + TB_BN - 1) / TB_BN;
     int tm, tn;
-    tile_coords(tiles_m, tiles_n, tm, tn);
+    tile_coords<8>(tiles_m, tiles_n, tm, tn);
     const int m0 = tm * TB_BM, n0 = tn * TB_BN;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -153,6 +160,160 @@ __global__ __launch_bounds__(256) void gemm_bf16_tile_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             epilogue_store4(g.ep, m0 + wm * 64 + i * 16 + r, n0 + wn * 64 + j * 16 + gq * 4, acc[j][i], g.M, g.N);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// bf16, 256x256x64, 8 waves (2 M x 4 N, 128x64 per wave = 32 accumulator tiles), LDS-DMA staging, ping-pong phases.
+//
+// * Both operand tiles go HBM/L2 -> LDS with global_load_lds (16 B per lane, no VGPR round trip, no ds_write pass).  A
+//   wave-instruction writes 8 rows x 128 B linearly; the XOR swizzle the fragment reads need (chunk c of row r in slot
+//   c ^ (r & 7): conflict-free ds_read_b128) is applied to the per-lane SOURCE address instead.
+// * A K tile (64 deep) is staged as four 16 KiB units -- A-lo / A-hi = the first / second 64 rows of each M wave-row,
+//   B-lo / B-hi = the first / second 32 columns of each N wave-column -- and computed as four phases of one 64x32
+//   quadrant (16 MFMAs per wave) each:  P1 A-lo x B-lo, P2 A-lo x B-hi, P3 A-hi x B-hi, P4 A-hi x B-lo.  A phase reads
+//   only the fragments that change (8 + 4, 4, 8, 4 ds_read_b128) and issues the LDS-DMA of ONE unit, two K tiles
+//   ahead at the earliest point its LDS slot is free (>= 2 phases after the slot's last read):
+//       P1: A-hi(t+1)   P2: B-lo(t+1)   P3: A-lo(t+2)   P4: B-hi(t+2)
+//   so there are always 2-3 units (32-48 KiB per CU) in flight and the DMA is never drained inside the loop: one counted
+//   s_waitcnt vmcnt(4) per K tile (in P4, one barrier before the first read of the tile it retires).
+// * The two M wave-rows run half a phase apart (waves 4-7 take one extra barrier up front, waves 0-3 one at the end):
+//   each SIMD holds one wave of either group, and while one issues its 16 MFMAs the other does its LDS reads and DMA
+//   issue, so the matrix pipe alternates between them instead of waiting for either.
+// LDS: 2 K-tile buffers x 4 units x 16 KiB = 128 KiB, one workgroup per CU.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int TL_BM = 256, TL_BN = 256, TL_BK = 64;
+constexpr int TL_UNIT = 128 * 128;                   // one staging unit: 128 rows x 64 bf16
+constexpr int TL_BUF = 4 * TL_UNIT;                  // one K tile: A-lo, A-hi, B-lo, B-hi
+constexpr int TL_SLAB_ROW = 64 * 4 + 16;              // epilogue slab row: 64 fp32 + 16 B pad
+constexpr int TL_SLAB = 64 * TL_SLAB_ROW;            // per wave: 64 rows
+constexpr int TL_LDS = (8 * TL_SLAB > 2 * TL_BUF) ? 8 * TL_SLAB : 2 * TL_BUF;
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__global__ __launch_bounds__(512) void gemm_bf16_tile256_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tiles_m = (g.M + TL_BM - 1) / TL_BM, tiles_n = (g.N + TL_BN - 1) / TL_BN;
+    int tm, tn;
+    tile_coords<4>(tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * TL_BM, n0 = tn * TL_BN;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 2, wn = wid & 3;
+    const int gq = lane >> 4, r = lane & 15;
+
+    // staging sources: unit U (0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi), piece j (0..1): unit-local rows (wid*2 + j)*8 .. +7
+    const bf16* src[4][2];
+    {
+        const bf16* A = reinterpret_cast<const bf16*>(g.A);
+        const bf16* W = reinterpret_cast<const bf16*>(g.W);
+        const int chunk = (lane & 7) ^ (lane >> 3);               // source chunk that lands in this lane's slot
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int u = (wid * 2 + j) * 8 + (lane >> 3);
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                int m = m0 + (u / 64) * 128 + hf * 64 + (u % 64); if (m > g.M - 1) m = g.M - 1;
+                int n = n0 + (u / 32) * 64 + hf * 32 + (u % 32); if (n > g.N - 1) n = g.N - 1;
+                src[hf][j] = A + a_row_offset(g, m) + chunk * 8;
+                src[2 + hf][j] = W + (int64_t)n * g.ldw + chunk * 8;
+            }
+        }
+    }
+    auto stage = [&](int unit, int kt) {
+        char* dst = lds + (kt & 1) * TL_BUF + unit * TL_UNIT + (wid * 2) * 1024;
+        const int k0 = kt * TL_BK;
+        __builtin_amdgcn_global_load_lds((gbl_void*)(src[unit][0] + k0), (lds_void*)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(src[unit][1] + k0), (lds_void*)(dst + 1024), 16, 0, 0);
+    };
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 xa[2][4], wf[2][2];
+    auto read_a = [&](const char* buf, int hf) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int u = wm * 64 + i * 16 + r;
+                xa[ks][i] = *reinterpret_cast<const bf16x8*>(buf + hf * TL_UNIT + u * 128 + (((ks * 4 + gq) ^ (r & 7)) << 4));
+            }
+    };
+    auto read_b = [&](const char* buf, int hf) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int u = wn * 32 + j * 16 + r;
+                wf[ks][j] = *reinterpret_cast<const bf16x8*>(buf + (2 + hf) * TL_UNIT + u * 128 + (((ks * 4 + gq) ^ (r & 7)) << 4));
+            }
+    };
+    auto mma = [&](int ha, int hb) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[hb * 2 + j][ha * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], xa[ks][i], acc[hb * 2 + j][ha * 4 + i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    // one K tile = four phases; S12 / S34: stage units of tile t+1 / t+2; WAIT: 4 = steady state, 0 = drain, -1 = none
+    auto ktile = [&](int t, auto S12, auto S34, auto WAIT) {
+        const char* buf = lds + (t & 1) * TL_BUF;
+        read_b(buf, 0); __builtin_amdgcn_sched_barrier(0); read_a(buf, 0);
+        if constexpr (decltype(S12)::value) stage(1, t + 1);
+        mma(0, 0);
+        read_b(buf, 1);
+        if constexpr (decltype(S12)::value) stage(2, t + 1);
+        mma(0, 1);
+        read_a(buf, 1);
+        if constexpr (decltype(S34)::value) stage(0, t + 2);
+        mma(1, 1);
+        read_b(buf, 0);
+        if constexpr (decltype(S34)::value) stage(3, t + 2);
+        if constexpr (decltype(WAIT)::value == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if constexpr (decltype(WAIT)::value == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        mma(1, 0);
+    };
+    using T_ = std::true_type; using F_ = std::false_type;
+    const int nk = g.K / TL_BK;                                   // launch_gemm guarantees nk >= 2
+    stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0); stage(0, 1); stage(3, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");              // tile 0 landed; A-lo(1), B-hi(1) still in flight
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();                    // waves 4-7 run half a phase behind waves 0-3
+    for (int t = 0; t + 2 < nk; ++t) ktile(t, T_{}, T_{}, std::integral_constant<int, 4>{});
+    ktile(nk - 2, T_{}, F_{}, std::integral_constant<int, 0>{});
+    ktile(nk - 1, F_{}, F_{}, std::integral_constant<int, -1>{});
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+    // Epilogue through LDS (the operand tiles are dead): an accumulator tile gives a lane 4 columns of 16 different
+    // rows, i.e. 32/64-B global segments; transposed through a wave-private LDS slab every global access of the epilogue
+    // (residual / positional loads, output stores) is instead 16 lanes x 16 B (8 B for bf16) along one row.  Two passes
+    // of 64 rows; slab rows padded to 272 B (conflict-free ds_write_b128 from the accumulator layout).
+    char* slab = lds + wid * TL_SLAB;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<f32x4*>(slab + (i * 16 + r) * TL_SLAB_ROW + (j * 16 + gq * 4) * 4) = acc[j][p * 4 + i];
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 4 + (lane >> 4), c = lane & 15;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * TL_SLAB_ROW + c * 16);
+            epilogue_store4(g.ep, m0 + wm * 128 + p * 64 + row, n0 + wn * 64 + c * 4, v, g.M, g.N);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -307,7 +468,7 @@ __global__ __launch_bounds__(256) void gemm_f32_tile_kernel(GemmArgs g) {
     constexpr int PA = BM * 4 / 256, PW = BN * 4 / 256;                   // float4 chunks per thread
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
     int tm, tn;
-    tile_coords(tiles_m, tiles_n, tm, tn);
+    tile_coords<8>(tiles_m, tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -397,8 +558,19 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
             if (!ok) return -1;
         } else {
             if (g.K % TB_BK != 0) return -1;
-            const int tiles = ((g.M + TB_BM - 1) / TB_BM) * ((g.N + TB_BN - 1) / TB_BN);
-            hipLaunchKernelGGL(gemm_bf16_tile_kernel, dim3(tiles), dim3(256), 0, st, g);
+            static const bool no256 = getenv("WX_NO_TILE256") != nullptr;
+            if (!no256 && g.M >= 4096 && g.N % TL_BN == 0 && g.K >= 2 * TL_BK) {
+                static bool attr_set = false;
+                if (!attr_set) {
+                    if (hipFuncSetAttribute((const void*)gemm_bf16_tile256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS) != hipSuccess) return -2;
+                    attr_set = true;
+                }
+                const int tiles = ((g.M + TL_BM - 1) / TL_BM) * (g.N / TL_BN);
+                hipLaunchKernelGGL(gemm_bf16_tile256_kernel, dim3(tiles), dim3(512), TL_LDS, st, g);
+            } else {
+                const int tiles = ((g.M + TB_BM - 1) / TB_BM) * ((g.N + TB_BN - 1) / TB_BN);
+                hipLaunchKernelGGL(gemm_bf16_tile_kernel, dim3(tiles), dim3(256), 0, st, g);
+            }
         }
     } else {
         if (g.K % TF_BK != 0) return -1;
