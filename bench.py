@@ -164,7 +164,7 @@ def main():
         avg_ms = prof_ms / max(1, prof_n)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if prof_n else 0.0
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "cross_attn_pmc.json")
+        pmc = os.path.join(ROOT, "profiles", "r01_cross_attn_pmc.json")
         if os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")

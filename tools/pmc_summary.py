@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 --pmc FETCH_SIZE pass (tools/pmc.sh): per-kernel mean FETCH_SIZE, corrected as
+MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE is in KiB and reports exactly half of the bytes of a wide
+coalesced streaming read: x 1024 x 2).  Writes the cross-attention kernel's figure as JSON for bench.py's `traffic`."""
+import csv, collections, glob, json, sys
+d = sys.argv[1]
+f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+agg = collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    if r["Counter_Name"] == "FETCH_SIZE":
+        agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+print(f"# {f}\n# FETCH_SIZE mean per launch, bytes = KiB x 1024 x 2 (gfx950 correction)")
+out = {}
+for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+    b = sum(v) / len(v) * 1024 * 2
+    print(f"{k[:80]:80s} launches={len(v):5d} hbm_bytes_per_launch={b:16.0f}")
+    if "attn_decode_kernel" in k:
+        out = {"kernel": k, "launches": len(v), "hbm_bytes_per_launch": b, "counter": "FETCH_SIZE (KiB) x 1024 x 2",
+               "source": "rocprofv3 --pmc FETCH_SIZE, own pass, bench.py --steps 1 --warmup 0 --max-new-tokens 4"}
+if len(sys.argv) > 2 and out:
+    json.dump(out, open(sys.argv[2], "w"), indent=1)
