@@ -73,6 +73,12 @@ int wx_set_mel_filters(wx_engine* e, const float* h_filters /* [n_mels][201] */)
 int wx_set_suppress_tokens(wx_engine* e, const int32_t* h_ids, int32_t n);
 int wx_finalize(wx_engine* e);
 
+/* replaces the tail of whisper.load_audio (inside model.transcribe, ref:speech_recognition.py:55): the reference's audio
+ * front end hands over 16 kHz mono s16le PCM (ref:app/audio/processor.py:141-143) and upstream divides by 32768 on the
+ * host; here the int16 samples are uploaded as they are (half the PCIe bytes) and converted on the device.
+ * d_pcm16 and d_out must be 16-byte aligned. */
+int wx_pcm16_to_f32(wx_engine* e, const int16_t* d_pcm16, int64_t n, float* d_out, void* stream);
+
 /* replaces whisper.log_mel_spectrogram inside Whisper.transcribe (ref:speech_recognition.py:55).
  * Stage 1: frames [frame0, frame0+n_frames) of the file -> d_logmel[m * ld + (f - frame0)] =
  *          log10(max(mel, 1e-10)), and atomically folds the slice maximum into *d_max (init with wx_mel_reset_max).

@@ -142,3 +142,27 @@ def test_properties_at_scale_bf16():
         assert torch.allclose(m2[:, 100:2900], mel[:, 100:2900], atol=1e-6)
     finally:
         eng.close()
+
+
+def test_pcm16_ingest_and_wav_path_bit_exact(tmp_path):
+    from oracle import whisper_oracle as wo
+    """Device-side PCM16 -> float32 (wx_pcm16_to_f32) equals the host /32768 conversion bit for bit, for aligned and
+    ragged lengths; a wav path and the equivalent float array give the same tokens."""
+    from whisper_amd import transcribe as tx
+    from whisper_amd.audio import save_wav_pcm16
+    eng = tx.configure(model="micro", precision="fp32", max_batch=2, allow_synthetic_weights=True)
+    try:
+        rng = np.random.default_rng(3)
+        for n in (1, 7, 8, 4099, 480000):
+            pcm = rng.integers(-32768, 32767, size=n, dtype=np.int16)
+            got = eng.pcm16_to_f32(pcm).cpu().numpy()
+            assert np.array_equal(got, pcm.astype(np.float32) / 32768.0)
+        audio = wo.varied_audio(5, 16000 * 33)
+        p = tmp_path / "clip.wav"
+        save_wav_pcm16(p, audio)
+        from whisper_amd.audio import load_wav_pcm16
+        a = tx.transcribe(str(p), language="en", max_new_tokens=8)
+        b = tx.transcribe(load_wav_pcm16(str(p)), language="en", max_new_tokens=8)
+        assert a["tokens"] == b["tokens"] and a["chunks_processed"] == 2
+    finally:
+        tx.close()

@@ -6,6 +6,8 @@ import importlib
 import os
 import sys
 
+from pathlib import Path
+
 import numpy as np
 import pytest
 import torch
@@ -142,3 +144,73 @@ def test_transcribe_requires_configuration():
         tx.transcribe(np.zeros(16000, np.float32))
     with pytest.raises(FileNotFoundError):
         tx.configure(model="base")       # no checkpoint and synthetic weights not allowed: never downloads
+
+
+def test_chunk_large_audio_matches_reference_arithmetic(tmp_path):
+    """ref:app/transcription/openai_whisper.py:236-255: no split at or under chunk_size_mb; otherwise pieces of
+    int(chunk_size_mb / file_size_mb * total_ms) milliseconds, named chunk_NNN<suffix> under <stem>_chunks/, covering the
+    file exactly once and in order."""
+    import asyncio
+    import wave
+    from whisper_amd.audio import load_wav_pcm16_raw
+    from whisper_amd.large_audio import chunk_large_audio
+    rng = np.random.default_rng(0)
+    pcm = rng.integers(-2000, 2000, size=16000 * 75, dtype=np.int16)      # 75 s = 2.29 MiB
+    p = tmp_path / "long.wav"
+    with wave.open(str(p), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(pcm.tobytes())
+    assert asyncio.run(chunk_large_audio(p, chunk_size_mb=20.0)) == [p]
+    chunks = asyncio.run(chunk_large_audio(p, chunk_size_mb=1.0))
+    size_mb = p.stat().st_size / (1024 * 1024)
+    chunk_ms = int(1.0 / size_mb * 75000)
+    assert len(chunks) == -(-75000 // chunk_ms)
+    assert [c.name for c in chunks] == [f"chunk_{i:03d}.wav" for i in range(len(chunks))]
+    assert chunks[0].parent == tmp_path / "long_chunks"
+    back = np.concatenate([load_wav_pcm16_raw(str(c)) for c in chunks])
+    assert np.array_equal(back, pcm)
+    for c in chunks[:-1]:
+        assert len(load_wav_pcm16_raw(str(c))) == chunk_ms * 16
+
+
+def test_transcribe_large_audio_prompt_carry_and_cleanup(tmp_path, monkeypatch):
+    """ref:openai_whisper.py:268-337 with the engine stubbed: one call under 25 MB; above it, pieces in order, the last 20
+    words of the previous piece in the prompt, text joined with spaces, mean confidence, modal language, source "chunked",
+    piece files and directory removed."""
+    import asyncio
+    import wave
+    from whisper_amd import large_audio as la
+    from whisper_amd import transcribe as tx
+    p = tmp_path / "big.wav"
+    with wave.open(str(p), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(np.zeros(16000 * 40, np.int16).tobytes())
+    calls = []
+
+    def fake(audio, language=None, prompt=None, **kw):
+        calls.append((Path(audio).name, language, prompt))
+        n = len(calls)
+        return {"text": " ".join(f"w{n}_{i}" for i in range(30)), "confidence": 0.2 * n, "language": "ru" if n != 2 else "en",
+                "chunks_processed": 1}
+    monkeypatch.setattr(tx, "transcribe", fake)
+    out = asyncio.run(la.transcribe_large_audio(p, True, "ru", "ctx"))
+    assert out[3] == "local" and calls == [("big.wav", "ru", "ctx")]
+    calls.clear()
+    monkeypatch.setattr(la, "MAX_SINGLE_CALL_MB", 0.5)
+
+    async def small_chunks(path, chunk_size_mb=20.0):
+        return await orig(path, 0.5)
+    orig = la.chunk_large_audio
+    monkeypatch.setattr(la, "chunk_large_audio", small_chunks)
+    text, conf, lang, source = asyncio.run(la.transcribe_large_audio(p, True, None, "ctx"))
+    assert source == "chunked" and len(calls) == 3 and lang == "ru"
+    assert [c[0] for c in calls] == ["chunk_000.wav", "chunk_001.wav", "chunk_002.wav"]
+    assert calls[0][2] == "ctx"
+    assert calls[1][2] == "ctx Previous context: " + " ".join(f"w1_{i}" for i in range(10, 30))
+    assert abs(conf - (0.2 + 0.4 + 0.6) / 3) < 1e-9
+    assert text.split()[0] == "w1_0" and text.split()[-1] == "w3_29" and len(text.split()) == 90
+    assert not (tmp_path / "big_chunks").exists()
+    # detailed=False: fixed text, confidence capped (ref:speech_recognition.py:69-72); a failing engine -> "failed"
+    calls.clear()
+    monkeypatch.setattr(la, "MAX_SINGLE_CALL_MB", 25)
+    assert asyncio.run(la.transcribe_large_audio(p, False))[:2] == ("Voice authentication required for full transcription", 0.2)
+    monkeypatch.setattr(tx, "transcribe", lambda *a, **k: (_ for _ in ()).throw(RuntimeError("boom")))
+    assert asyncio.run(la.transcribe_large_audio(p)) == ("", 0.0, "unknown", "failed")

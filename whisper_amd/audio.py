@@ -77,6 +77,19 @@ def load_wav_pcm16(path: str) -> np.ndarray:
     return raw.astype(np.float32) / 32768.0
 
 
+def load_wav_pcm16_raw(path: str) -> np.ndarray:
+    """Same file contract as :func:`load_wav_pcm16`, but returns the int16 samples untouched (mono files only) so the
+    /32768 conversion can run on the GPU (``WhisperEngine.pcm16_to_f32``)."""
+    with wave.open(str(path), "rb") as w:
+        if w.getsampwidth() != 2:
+            raise ValueError(f"{path}: expected 16-bit PCM, got sample width {w.getsampwidth()}")
+        if w.getframerate() != SAMPLE_RATE:
+            raise ValueError(f"{path}: expected {SAMPLE_RATE} Hz, got {w.getframerate()} (normalise with app/audio first)")
+        if w.getnchannels() != 1:
+            raise ValueError(f"{path}: expected mono")
+        return np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
+
+
 def save_wav_pcm16(path: str, audio: np.ndarray) -> None:
     pcm = np.clip(np.round(np.asarray(audio, np.float64) * 32768.0), -32768, 32767).astype("<i2")
     with wave.open(str(path), "wb") as w:

@@ -101,6 +101,7 @@ int launch_mel_stage1(const MelTables& t, const float* pcm, int64_t pcm_offset, 
                       hipStream_t st);
 int launch_mel_stage2(float* x, int64_t ld, int n_mels, int64_t n_frames, const float* d_max, hipStream_t st);
 int launch_fill_f32(float* p, float v, int64_t n, hipStream_t st);
+int launch_pcm16_to_f32(const int16_t* in, float* out, int64_t n, hipStream_t st);   // x / 32768
 
 // ---- attention ----------------------------------------------------------------------------------------
 struct AttnArgs {

@@ -434,6 +434,12 @@ int wx_finalize(wx_engine* e) {
     return WX_OK;
 }
 
+int wx_pcm16_to_f32(wx_engine* e, const int16_t* d_pcm16, int64_t n, float* d_out, void* stream) {
+    if (!e || !d_pcm16 || !d_out || n < 0) return fail(WX_ERR_INVALID, "bad argument");
+    WX_TRY(launch_pcm16_to_f32(d_pcm16, d_out, n, (hipStream_t)stream));
+    return WX_OK;
+}
+
 int wx_mel_reset_max(wx_engine* e, float* d_max, void* stream) {
     if (!e || !d_max) return fail(WX_ERR_INVALID, "bad argument");
     WX_TRY(launch_fill_f32(d_max, -INFINITY, 1, (hipStream_t)stream));

@@ -142,6 +142,32 @@ __global__ void mel_stage2_kernel(float* __restrict__ x, int64_t ld, int n_mels,
     }
 }
 
+// PCM16 -> float32 in [-1, 1): x / 32768, the scaling upstream load_audio applies after ffmpeg (exact in fp32).
+// 8 samples (16 B in, 32 B out) per lane.
+__global__ void pcm16_to_f32_kernel(const int16_t* __restrict__ in, float* __restrict__ out, int64_t n) {
+    const int64_t n8 = n / 8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        typedef __attribute__((ext_vector_type(8))) short i16x8;
+        const i16x8 v = *reinterpret_cast<const i16x8*>(in + i * 8);
+        f32x4 a, b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] = (float)v[j] * (1.0f / 32768.0f); b[j] = (float)v[4 + j] * (1.0f / 32768.0f); }
+        *reinterpret_cast<f32x4*>(out + i * 8) = a;
+        *reinterpret_cast<f32x4*>(out + i * 8 + 4) = b;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n - n8 * 8) out[n8 * 8 + threadIdx.x] = (float)in[n8 * 8 + threadIdx.x] * (1.0f / 32768.0f);
+}
+
+int launch_pcm16_to_f32(const int16_t* in, float* out, int64_t n, hipStream_t st) {
+    if (n <= 0) return 0;
+    if ((reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return -1;
+    int64_t blocks = (n / 8 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(pcm16_to_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, n);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 __global__ void fill_f32_kernel(float* p, float v, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }

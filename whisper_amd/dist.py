@@ -88,12 +88,14 @@ def transcribe_sharded(engine, audio: np.ndarray, prompt: Sequence[int], group=N
     """Every rank passes the same host ``audio``; each uploads and processes only its own windows.  All ranks return
     the full, window-ordered result."""
     rank, world = rank_world(group)
-    audio = np.ascontiguousarray(np.asarray(audio, dtype=np.float32))
+    is_pcm16 = isinstance(audio, np.ndarray) and audio.dtype == np.int16     # raw samples: converted on the device
+    audio = np.ascontiguousarray(audio if is_pcm16 else np.asarray(audio, dtype=np.float32))
     n_file = int(audio.shape[0])
     nw = n_windows(n_file)
     w_lo, w_hi = shard_range(nw, rank, world)
     s_lo, s_hi = local_sample_range(n_file, w_lo, w_hi)
-    pcm_local = torch.from_numpy(audio[s_lo:max(s_hi, s_lo + 1)] if s_hi > s_lo else np.zeros(1, np.float32)).to(engine.torch_device)
+    local = audio[s_lo:max(s_hi, s_lo + 1)] if s_hi > s_lo else np.zeros(1, audio.dtype)
+    pcm_local = engine.pcm16_to_f32(local) if is_pcm16 else torch.from_numpy(local).to(engine.torch_device)
     mel = sharded_mel(engine, pcm_local, s_lo, n_file, w_lo, w_hi, group)
     content = n_file // HOP_LENGTH
     if w_hi > w_lo:

@@ -93,6 +93,18 @@ class WhisperEngine:
     def workspace_bytes(self) -> int:
         return int(self.lib.wx_workspace_bytes(self.handle))
 
+    # -- audio ingest ---------------------------------------------------------------------------------------
+    def pcm16_to_f32(self, pcm16) -> torch.Tensor:
+        """int16 PCM (numpy array or tensor) -> float32 samples in [-1, 1) on the device (x / 32768, converted by the
+        HIP kernel: the int16 samples cross PCIe, not float32)."""
+        t = torch.from_numpy(np.array(pcm16, copy=True)) if not torch.is_tensor(pcm16) else pcm16
+        if t.dtype != torch.int16:
+            raise ValueError("pcm16_to_f32 expects int16 samples")
+        t = t.to(self.torch_device).contiguous()
+        out = torch.empty(t.numel(), dtype=torch.float32, device=self.torch_device)
+        _lib.check(self.lib.wx_pcm16_to_f32(self.handle, _ptr(t), t.numel(), _ptr(out), self._stream()), "wx_pcm16_to_f32")
+        return out
+
     # -- mel ----------------------------------------------------------------------------------------------
     def mel_stage1(self, pcm: torch.Tensor, pcm_offset: int, n_file: int, n_total: int, frame0: int, n_frames: int,
                    out: torch.Tensor, gmax: torch.Tensor) -> None:

@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import checkpoint as ck
-from .audio import N_FRAMES, N_SAMPLES, load_wav_pcm16
+from .audio import N_FRAMES, N_SAMPLES, load_wav_pcm16, load_wav_pcm16_raw
 from .tokenizer import LANGUAGE_CODES, Tokenizer, language_index
 
 logger = logging.getLogger(__name__)
@@ -78,12 +78,17 @@ def get_tokenizer() -> Tokenizer:
 
 def _load_audio(audio: Union[str, Path, np.ndarray, torch.Tensor]) -> np.ndarray:
     if isinstance(audio, (str, Path)):
-        return load_wav_pcm16(str(audio))
+        try:
+            return load_wav_pcm16_raw(str(audio))     # int16: uploaded as is, /32768 on the GPU
+        except ValueError:
+            return load_wav_pcm16(str(audio))         # multi-channel: averaged on the host
     if torch.is_tensor(audio):
         audio = audio.detach().cpu().numpy()
     a = np.asarray(audio)
     if a.ndim != 1:
         raise ValueError("audio must be mono (1-D float32 at 16 kHz)")
+    if a.dtype == np.int16:
+        return np.ascontiguousarray(a)
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
@@ -127,7 +132,8 @@ def transcribe(audio, language: Optional[str] = None, prompt: Union[None, str, S
     n_file = int(pcm_host.shape[0])
     if language is None:
         # language id needs the first window only; every rank computes it (identical result, no exchange needed)
-        first = torch.from_numpy(pcm_host[: min(n_file, N_SAMPLES)]).to(eng.torch_device)
+        head = pcm_host[: min(n_file, N_SAMPLES)]
+        first = eng.pcm16_to_f32(head) if head.dtype == np.int16 else torch.from_numpy(head).to(eng.torch_device)
         mel0 = eng.log_mel(first)
         lang_idx = detect_language(eng, mel0, min(n_file, N_SAMPLES) // 160)
     else:
