@@ -183,7 +183,7 @@ def main():
                 "hip_graph": not args.no_graph, "parallelism": f"window-dp{world}",
             },
             "roofline": {
-                "kernel": "attn_decode_kernel<bf16> (decoder cross-attention)" if es == 2 else "attn_decode_kernel<float>",
+                "kernel": "attn_decode_kernel<bf16,1> (decoder cross-attention)" if es == 2 else "attn_decode_kernel<float>",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms, "launches_timed": prof_n,

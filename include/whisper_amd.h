@@ -110,6 +110,22 @@ int wx_decode_greedy(wx_engine* e, int32_t B, const int32_t* h_prompt, const wx_
                      int32_t* d_tokens, int32_t* d_n_tokens, float* d_sum_logprob, float* d_no_speech_prob,
                      int32_t* h_steps, void* stream);
 
+/* replaces DecodingTask.run with BeamSearchDecoder (upstream beam_size / patience options; the reference itself never
+ * sets them -- ref:speech_recognition.py:48-52 -- but BASELINE.json configs[3] does) for the B windows of the last
+ * wx_encode.  Rows = B x beam_size must fit max_batch.  The device runs upstream's update() every step: per window the
+ * beam_size+1 best continuations of every beam, visited best first, EOT candidates appended to the window's finished
+ * list while it holds fewer than max_candidates = round(beam_size * patience) entries, the first beam_size others kept as
+ * beams; decoding stops when every window's list is full (or at sample_len).  The self-attention cache follows the
+ * beams through index rows (no K/V copy); the beams of a window share one pass over its cross-attention K/V.
+ * Outputs (device): d_fin_tokens [B][max_candidates][n_text_ctx] (prompt + ids + EOT padding, in finished order),
+ * d_fin_sum_logprob [B][max_candidates], d_fin_count [B], and the live beams d_beam_tokens [B*beam_size][n_text_ctx],
+ * d_beam_sum_logprob [B*beam_size] -- upstream finalize() (top up short lists from the beams) and the
+ * sum_logprob / length ranking are a few dozen host operations and are left to the caller (whisper_amd/engine.py). */
+int wx_decode_beam(wx_engine* e, int32_t B, int32_t beam_size, float patience, const int32_t* h_prompt,
+                   const wx_decode_opts* opts, int32_t* d_fin_tokens, float* d_fin_sum_logprob, int32_t* d_fin_count,
+                   int32_t* d_beam_tokens, float* d_beam_sum_logprob, float* d_no_speech_prob, int32_t* h_steps,
+                   void* stream);
+
 /* replaces TextDecoder.forward (teacher forced): logits of every position of d_tokens [B][n] against the
  * last wx_encode, written to d_logits [B][n][n_vocab] fp32.  Parity/debug entry point. */
 int wx_decoder_logits(wx_engine* e, int32_t B, const int32_t* d_tokens, int32_t n, float* d_logits, void* stream);

@@ -362,6 +362,119 @@ def greedy_decode(model: OracleWhisper, xa: torch.Tensor, init_tokens: Sequence[
             "raw_tokens": tokens.numpy()}
 
 
+def beam_search_decode(model: OracleWhisper, xa: torch.Tensor, init_tokens: Sequence[int], tok,
+                       suppress_ids: Sequence[int], beam_size: int = 5, patience: float = 1.0,
+                       max_new_tokens: Optional[int] = None, without_timestamps: bool = True,
+                       suppress_blank: bool = True) -> Dict[str, object]:
+    """Upstream ``DecodingTask`` with ``BeamSearchDecoder`` (temperature 0, ``beam_size`` given) [upstream-recall: the
+    openai-whisper source is not in this container; transformers' beam search is a different algorithm, so this
+    function is NOT pinned by the HF golden vectors -- parity of the beam path is unpinned, the GPU path is checked
+    against this restatement only].
+
+    Per step, per audio: every beam proposes its ``beam_size + 1`` best tokens of log_softmax(filtered logits);
+    candidates are keyed by the full sequence (at the first step all beams hold the same prefix, so they collapse to
+    one beam's proposals); candidates are visited by cumulative log-probability, best first: a candidate ending in EOT
+    goes to the audio's finished list, any other becomes a beam, until ``beam_size`` beams are kept.  Newly finished
+    sequences are appended best-first while the list has fewer than ``max_candidates = round(beam_size * patience)``
+    entries; decoding stops when every audio has that many (or after ``sample_len`` steps / ``n_text_ctx`` tokens).  The
+    self-attention cache follows the beams (``rearrange_kv_cache``).  ``finalize`` tops short lists up with the live
+    beams (best first, EOT appended); the result is the finished sequence with the highest sum_logprob / length
+    (``MaximumLikelihoodRanker``, ``length_penalty=None``).
+
+    Returns tokens (per audio, without EOT), sum_logprobs of the selected sequence, avg_logprobs, no_speech_probs,
+    steps, and ``candidates`` (per audio: list of (tokens, sum_logprob) in finished-list order)."""
+    dims = model.dims
+    n_audio = xa.shape[0]
+    n = beam_size
+    max_candidates = round(beam_size * patience)
+    sample_len = dims.n_text_ctx // 2 if max_new_tokens is None else max_new_tokens
+    init = list(init_tokens)
+    sample_begin = len(init)
+    sot_index = init.index(tok.sot)
+    tokens = torch.tensor([init] * (n_audio * n), dtype=torch.long)
+    xa_rep = xa.repeat_interleave(n, dim=0)
+    cross = model.cross_kv(xa_rep)
+    cache: List = []
+    sum_logprobs = torch.zeros(n_audio * n)
+    finished_sequences: List[Dict] = [{} for _ in range(n_audio)]
+    no_speech = torch.zeros(n_audio * n)
+    steps = 0
+    for i in range(sample_len):
+        if i == 0:
+            lg_all = model.decode_step(tokens, 0, cross, cache)
+            no_speech = lg_all[:, sot_index].float().softmax(-1)[:, tok.no_speech].clone()
+            lg = lg_all[:, -1].clone()
+        else:
+            lg = model.decode_step(tokens[:, -1:], tokens.shape[1] - 1, cross, cache)[:, -1].clone()
+        if suppress_blank and tokens.shape[1] == sample_begin:
+            lg[:, [tok.blank, tok.eot]] = -np.inf
+        lg[:, list(suppress_ids)] = -np.inf
+        if not without_timestamps:
+            apply_timestamp_rules(lg, tokens, sample_begin, tok)
+        logprobs = F.log_softmax(lg.float(), dim=-1)
+        next_tokens, source_indices, newly = [], [], []
+        new_sums = sum_logprobs.clone()
+        for a in range(n_audio):
+            scores, sources, finished = {}, {}, {}
+            for j in range(n):
+                idx = a * n + j
+                prefix = tokens[idx].tolist()
+                vals, ids = logprobs[idx].topk(n + 1)
+                for logprob, token in zip(vals, ids):
+                    seq = tuple(prefix + [int(token)])
+                    scores[seq] = float(sum_logprobs[idx] + logprob)
+                    sources[seq] = idx
+            saved = 0
+            for seq in sorted(scores, key=scores.get, reverse=True):
+                if seq[-1] == tok.eot:
+                    finished[seq] = scores[seq]
+                else:
+                    new_sums[len(next_tokens)] = scores[seq]
+                    next_tokens.append(seq)
+                    source_indices.append(sources[seq])
+                    saved += 1
+                    if saved == n:
+                        break
+            newly.append(finished)
+        sum_logprobs = new_sums
+        tokens = torch.tensor(next_tokens, dtype=torch.long)
+        src = torch.tensor(source_indices)
+        for layer in cache:                       # rearrange_kv_cache
+            layer[0] = layer[0][src]
+            layer[1] = layer[1][src]
+        for prev, new in zip(finished_sequences, newly):
+            for seq in sorted(new, key=new.get, reverse=True):
+                if len(prev) >= max_candidates:
+                    break
+                prev[seq] = new[seq]
+        steps += 1
+        completed = all(len(f) >= max_candidates for f in finished_sequences)
+        if completed or tokens.shape[-1] > dims.n_text_ctx:
+            break
+    # finalize
+    tok3 = tokens.reshape(n_audio, n, -1)
+    sums2 = sum_logprobs.reshape(n_audio, n)
+    for a, seqs in enumerate(finished_sequences):
+        if len(seqs) < n:
+            for j in list(np.argsort(sums2[a].numpy()))[::-1]:
+                seq = tok3[a, j].tolist() + [tok.eot]
+                seqs[tuple(seq)] = float(sums2[a, j])
+                if len(seqs) >= n:
+                    break
+    out_tokens, out_sums, cands = [], [], []
+    for a, seqs in enumerate(finished_sequences):
+        items = []
+        for seq, sc in seqs.items():
+            body = list(seq[sample_begin:])
+            body = body[:body.index(tok.eot)]
+            items.append((body, sc))
+        best = int(np.argmax([sc / len(body) if len(body) > 0 else -np.inf for body, sc in items])) if any(len(b) for b, _ in items) else 0
+        out_tokens.append(items[best][0]); out_sums.append(items[best][1]); cands.append(items)
+    avg = [out_sums[a] / (len(out_tokens[a]) + 1) for a in range(n_audio)]
+    return {"tokens": out_tokens, "sum_logprobs": np.array(out_sums, np.float32), "avg_logprobs": np.array(avg, np.float32),
+            "no_speech_probs": no_speech.reshape(n_audio, n)[:, 0].numpy(), "steps": steps, "candidates": cands}
+
+
 def transcribe_windows(model: OracleWhisper, audio: np.ndarray, init_tokens: Sequence[int], tok,
                        suppress_ids: Sequence[int], max_new_tokens: Optional[int] = None,
                        without_timestamps: bool = True, batch: int = 8) -> Dict[str, object]:

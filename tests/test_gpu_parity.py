@@ -194,3 +194,54 @@ def test_bf16_greedy_agrees_with_oracle_where_margin_is_large(models):
             if ref["margins"][i, b] < 0.15:      # bf16 logits move by O(1e-2): stop comparing at the first close call
                 break
             assert int(t[b, len(init) + i]) == want
+
+
+@pytest.mark.parametrize("name,beam,boost,use_graph", [("micro", 5, 3.0, True), ("micro", 5, 6.0, False), ("tiny", 3, 3.0, True),
+                                                     ("micro", 8, 6.0, True)])
+def test_beam_search_matches_oracle_fp32(models, name, beam, boost, use_graph):
+    """Beam search (BASELINE configs[3]) in fp32 mode: the selected ids, every finished candidate (order included) and their
+    cumulative log-probabilities equal the oracle's restatement of upstream BeamSearchDecoder.  eot_boost 6 makes EOT a
+    frequent proposal, so finished lists fill up and decoding stops early; boost 3 mostly ends at sample_len and
+    exercises finalize()'s top-up from the live beams."""
+    max_batch = 3 * beam
+    dims, sd, eng = models(name, "fp32", max_batch=max_batch, eot_boost=boost)
+    om = wo.OracleWhisper(dims, sd)
+    tok = eng.tok
+    mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(s), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000] for s in range(3)])
+    init = wo.initial_tokens(tok, 0)
+    with torch.no_grad():
+        ref = wo.beam_search_decode(om, om.encode(mels), init, tok, wo.suppress_token_ids(tok, ck.non_speech_suppress_ids()),
+                                    beam_size=beam, max_new_tokens=24)
+    eng.encode_windows(mels)
+    got = eng.decode_beam(3, init, beam_size=beam, max_new_tokens=24, use_graph=use_graph, check_interval=1)
+    assert got["tokens"] == ref["tokens"]
+    assert got["steps"] == ref["steps"]
+    np.testing.assert_allclose(got["sum_logprobs"], ref["sum_logprobs"], rtol=1e-4, atol=2e-3)
+    for b in range(3):
+        assert [c[0] for c in got["candidates"][b]] == [c[0] for c in ref["candidates"][b]]
+        np.testing.assert_allclose([c[1] for c in got["candidates"][b]], [c[1] for c in ref["candidates"][b]], rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(got["no_speech_probs"], ref["no_speech_probs"], rtol=1e-3, atol=1e-6)
+    # greedy afterwards on the same engine still works (the self-attention cache switches back to 16-token pages)
+    r = eng.decode_greedy(3, init, max_new_tokens=8)
+    with torch.no_grad():
+        g = wo.greedy_decode(om, om.encode(mels), init, tok, wo.suppress_token_ids(tok, ck.non_speech_suppress_ids()), max_new_tokens=8)
+    t, n = r["tokens"].cpu(), r["n_tokens"].cpu()
+    assert [t[b, len(init):len(init) + int(n[b])].tolist() for b in range(3)] == g["tokens"]
+
+
+def test_beam_search_bf16_shares_cross_kv(models):
+    """bf16 beam search at width 5 runs (rows = 15 <= 64: split-K decode GEMMs, grouped cross-attention) and beam width 1
+    reproduces greedy decoding exactly."""
+    dims, sd, eng = models("micro256", "bf16", max_batch=15, attn_gain=1.0, eot_boost=3.0)
+    mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(s), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000] for s in range(3)])
+    init = wo.initial_tokens(eng.tok, 0)
+    eng.encode_windows(mels)
+    g = eng.decode_greedy(3, init, max_new_tokens=16)
+    t, n = g["tokens"].cpu(), g["n_tokens"].cpu()
+    greedy = [t[b, len(init):len(init) + int(n[b])].tolist() for b in range(3)]
+    b1 = eng.decode_beam(3, init, beam_size=1, max_new_tokens=16)
+    assert b1["tokens"] == greedy
+    b5 = eng.decode_beam(3, init, beam_size=5, max_new_tokens=16)
+    assert len(b5["tokens"]) == 3 and all(len(c) >= 5 for c in b5["candidates"])
+    for b in range(3):     # the best beam can only score at least as well as the greedy path under the same model
+        assert max(c[1] / max(len(c[0]), 1) for c in b5["candidates"][b]) >= g["sum_logprobs"].cpu()[b].item() / max(len(greedy[b]), 1) - 1e-2

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256 * NWH) void attn_self_decode_kernel(AttnArgs a)
     typedef Chunk<T> C;
     constexpr int EPL = C::EPL, LPK = HEAD_DIM / EPL, KPI = 64 / LPK, U = 8, IT = KPI * U;
     __shared__ float s_row[4][3][HEAD_DIM];
-    __shared__ int s_pt[4][64];
+    __shared__ int s_pt[4][448];                 // page-table row (page size 16: 28 entries; page size 1: n_text_ctx)
     __shared__ float s_m[4][NWH], s_l[4][NWH];
     __shared__ float s_o[4][NWH][HEAD_DIM];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -115,8 +115,9 @@ __global__ __launch_bounds__(256 * NWH) void attn_self_decode_kernel(AttnArgs a)
     const int b = bh / a.H, h = bh % a.H;
     const int sub = lane % LPK, grp = lane / LPK;
     const int t_cur = *a.d_pos, n_keys = t_cur + 1;
+    const int PS = a.page_size;
     if (kw == 0) {
-        if (lane < a.pt_ld) s_pt[hs][lane] = a.page_table[b * a.pt_ld + lane];
+        for (int i = lane; i < a.pt_ld; i += 64) s_pt[hs][i] = a.page_table[b * a.pt_ld + i];
         float rows[3];
         load_head_rows<T, 3>(a, b, h, lane, rows);
 #pragma unroll
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256 * NWH) void attn_self_decode_kernel(AttnArgs a)
     T* Kp = reinterpret_cast<T*>(a.Kpool);
     T* Vp = reinterpret_cast<T*>(a.Vpool);
     if (valid && kw == 0 && lane < LPK) {     // append this step's key/value row to the page of position t_cur
-        const int64_t off = (((int64_t)s_pt[hs][t_cur / KV_PAGE] * a.H + h) * KV_PAGE + t_cur % KV_PAGE) * HEAD_DIM + sub * EPL;
+        const int64_t off = (((int64_t)s_pt[hs][t_cur / PS] * a.H + h) * PS + t_cur % PS) * HEAD_DIM + sub * EPL;
         *reinterpret_cast<typename C::Raw*>(Kp + off) = kn_r;
         *reinterpret_cast<typename C::Raw*>(Vp + off) = vn_r;
     }
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256 * NWH) void attn_self_decode_kernel(AttnArgs a)
             if (key > n_keys - 1) key = n_keys - 1;
             // the slot of position t_cur is being written by this launch: it is read (address valid, value ignored)
             // and replaced by the register copy
-            const int64_t off = (((int64_t)s_pt[hs][key / KV_PAGE] * a.H + h) * KV_PAGE + key % KV_PAGE) * HEAD_DIM + sub * EPL;
+            const int64_t off = (((int64_t)s_pt[hs][key / PS] * a.H + h) * PS + key % PS) * HEAD_DIM + sub * EPL;
             kr[u] = __builtin_nontemporal_load(reinterpret_cast<const typename C::Raw*>(Kp + off));
             vr[u] = __builtin_nontemporal_load(reinterpret_cast<const typename C::Raw*>(Vp + off));
             if (key == t_cur) { kr[u] = kn_r; vr[u] = vn_r; }
@@ -213,37 +214,46 @@ __global__ __launch_bounds__(256 * NWH) void attn_self_decode_kernel(AttnArgs a)
     }
 }
 
-// Decoder cross-attention over the cached encoder K/V (dense [B][H][n_keys][64]): one workgroup per (b, h) and key split,
-// its four waves interleave the key iterations.
-template <typename T>
+// Decoder cross-attention over the cached encoder K/V (dense [windows][H][n_keys][64]): one workgroup per (window, head)
+// and key split; its four waves interleave the key iterations.  NQ query rows (the beams of the window, kv_group of
+// them) share every K/V load: beam search at width 5 streams the cache once per step, not five times.
+template <typename T, int NQ>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     typedef Chunk<T> C;
     constexpr int EPL = C::EPL, LPK = HEAD_DIM / EPL, KPI = 64 / LPK, U = 8, IT = KPI * U;
-    __shared__ float s_m[4], s_l[4];
-    __shared__ float s_o[4][HEAD_DIM];
-    __shared__ float s_q[HEAD_DIM];
-    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H, split = blockIdx.y;
+    __shared__ float s_m[4][NQ], s_l[4][NQ];
+    __shared__ float s_o[4][NQ][HEAD_DIM];
+    __shared__ float s_q[NQ][HEAD_DIM];
+    const int w = blockIdx.x / a.H, h = blockIdx.x % a.H, split = blockIdx.y;     // w: K/V entry (window)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int sub = lane % LPK, grp = lane / LPK;
     const int n_keys = a.n_keys;
-    if (wid == 0) {
+    const int row0 = w * a.kv_group;
+    for (int q = wid; q < NQ; q += 4) {
+        int row = row0 + (q < a.kv_group ? q : a.kv_group - 1);      // NQ may round kv_group up: extra slots repeat the last row
+        if (row > a.B - 1) row = a.B - 1;
         float rows[1];
-        load_head_rows<T, 1>(a, b, h, lane, rows);
-        s_q[lane] = rows[0];
+        load_head_rows<T, 1>(a, row, h, lane, rows);
+        s_q[q][lane] = rows[0];
     }
     __syncthreads();
-    float qf[EPL];
+    float qf[NQ][EPL];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) qf[e] = s_q[sub * EPL + e];
-    const T* kbase = reinterpret_cast<const T*>(a.K) + ((int64_t)b * a.H + h) * a.kv_sbh + sub * EPL;
-    const T* vbase = reinterpret_cast<const T*>(a.V) + ((int64_t)b * a.H + h) * a.kv_sbh + sub * EPL;
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) qf[q][e] = s_q[q][sub * EPL + e];
+    const T* kbase = reinterpret_cast<const T*>(a.K) + ((int64_t)w * a.H + h) * a.kv_sbh + sub * EPL;
+    const T* vbase = reinterpret_cast<const T*>(a.V) + ((int64_t)w * a.H + h) * a.kv_sbh + sub * EPL;
     const int total_it = (n_keys + IT - 1) / IT;
     const int it0 = (int)((int64_t)split * total_it / a.n_split), it1 = (int)((int64_t)(split + 1) * total_it / a.n_split);
 
-    float m = -INFINITY, l = 0.f, o[EPL];
+    float m[NQ], l[NQ], o[NQ][EPL];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) o[e] = 0.f;
-
+    for (int q = 0; q < NQ; ++q) {
+        m[q] = -INFINITY; l[q] = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o[q][e] = 0.f;
+    }
     for (int it = it0 + wid; it < it1; it += 4) {
         typename C::Raw kr[U], vr[U];
         const int key0 = it * IT + grp;
@@ -254,67 +264,80 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
             kr[u] = __builtin_nontemporal_load(reinterpret_cast<const typename C::Raw*>(kbase + (int64_t)key * HEAD_DIM));
             vr[u] = __builtin_nontemporal_load(reinterpret_cast<const typename C::Raw*>(vbase + (int64_t)key * HEAD_DIM));
         }
-        float s[U];
-        float mt = -INFINITY;
+        float s[NQ][U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float kf[EPL];
             C::unpack(kr[u], kf);
-            float d = 0.f;
+            const bool valid = key0 + u * KPI < n_keys;
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) d = fmaf(qf[e], kf[e], d);
-            d = group_sum<LPK>(d);
-            s[u] = (key0 + u * KPI < n_keys) ? d : -INFINITY;
-            mt = fmaxf(mt, s[u]);
-        }
-        if (mt > -INFINITY) {
-            const float mn = fmaxf(m, mt);
-            const float alpha = (m == -INFINITY) ? 0.f : exp2f((m - mn) * LOG2E);
-            l *= alpha;
+            for (int q = 0; q < NQ; ++q) {
+                float d = 0.f;
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) o[e] *= alpha;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const float p = exp2f((s[u] - mn) * LOG2E);   // exp2(-inf) = 0 for masked keys
-                l += p;
-                float vf[EPL];
-                C::unpack(vr[u], vf);
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) o[e] = fmaf(p, vf[e], o[e]);
+                for (int e = 0; e < EPL; ++e) d = fmaf(qf[q][e], kf[e], d);
+                d = group_sum<LPK>(d);
+                s[q][u] = valid ? d : -INFINITY;
             }
-            m = mn;
+        }
+        float vf[U][EPL];
+#pragma unroll
+        for (int u = 0; u < U; ++u) C::unpack(vr[u], vf[u]);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            float mt = s[q][0];
+#pragma unroll
+            for (int u = 1; u < U; ++u) mt = fmaxf(mt, s[q][u]);
+            if (mt > -INFINITY) {
+                const float mn = fmaxf(m[q], mt);
+                const float alpha = (m[q] == -INFINITY) ? 0.f : exp2f((m[q] - mn) * LOG2E);
+                l[q] *= alpha;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) o[q][e] *= alpha;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float p = exp2f((s[q][u] - mn) * LOG2E);   // exp2(-inf) = 0 for masked keys
+                    l[q] += p;
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) o[q][e] = fmaf(p, vf[u][e], o[q][e]);
+                }
+                m[q] = mn;
+            }
         }
     }
     // merge the KPI lane groups of the wave (lanes that hold the same 16-B chunk of the head)
 #pragma unroll
-    for (int off = LPK; off < 64; off <<= 1) {
-        const float m2 = __shfl_xor(m, off), l2 = __shfl_xor(l, off);
-        float o2[EPL];
+    for (int q = 0; q < NQ; ++q) {
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) o2[e] = __shfl_xor(o[e], off);
-        merge_state<EPL>(m, l, o, m2, l2, o2);
-    }
-    if (lane < LPK) {
-        if (lane == 0) { s_m[wid] = m; s_l[wid] = l; }
+        for (int off = LPK; off < 64; off <<= 1) {
+            const float m2 = __shfl_xor(m[q], off), l2 = __shfl_xor(l[q], off);
+            float o2[EPL];
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) s_o[wid][sub * EPL + e] = o[e];
+            for (int e = 0; e < EPL; ++e) o2[e] = __shfl_xor(o[q][e], off);
+            merge_state<EPL>(m[q], l[q], o[q], m2, l2, o2);
+        }
+        if (lane < LPK) {
+            if (lane == 0) { s_m[wid][q] = m[q]; s_l[wid][q] = l[q]; }
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) s_o[wid][q][sub * EPL + e] = o[q][e];
+        }
     }
     __syncthreads();
-    if (threadIdx.x < HEAD_DIM) {
-        const int d = threadIdx.x;
-        float M = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+    for (int q = wid; q < NQ; q += 4) {
+        const int row = row0 + q;
+        if (q >= a.kv_group || row >= a.B) continue;
+        const int d = lane;
+        const float M = fmaxf(fmaxf(s_m[0][q], s_m[1][q]), fmaxf(s_m[2][q], s_m[3][q]));
         float L = 0.f, acc = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float f = (s_m[w] == -INFINITY) ? 0.f : exp2f((s_m[w] - M) * LOG2E);
-            L += s_l[w] * f;
-            acc += s_o[w][d] * f;
+        for (int ww = 0; ww < 4; ++ww) {
+            const float f = (s_m[ww][q] == -INFINITY) ? 0.f : exp2f((s_m[ww][q] - M) * LOG2E);
+            L += s_l[ww][q] * f;
+            acc += s_o[ww][q][d] * f;
         }
         if (a.n_split == 1) {
-            T* op = reinterpret_cast<T*>(a.O) + (int64_t)b * a.o_sb + h * a.o_sh + d;
-            *op = (T)(acc / L);
+            reinterpret_cast<T*>(a.O)[(int64_t)row * a.o_sb + h * a.o_sh + d] = (T)(acc / L);
         } else {
-            float* pp = a.partial + ((int64_t)blockIdx.x * a.n_split + split) * (HEAD_DIM + 2);
+            float* pp = a.partial + (((int64_t)row * a.H + h) * a.n_split + split) * (HEAD_DIM + 2);
             pp[d] = acc;
             if (d == 0) { pp[HEAD_DIM] = M; pp[HEAD_DIM + 1] = L; }
         }
@@ -453,7 +476,7 @@ int launch_attn_decode(const AttnArgs& a, hipStream_t st) {
     if (a.n_q != 1 || a.n_split < 1) return -1;
     const bool paged = a.page_table != nullptr;
     if (paged) {
-        if (!a.d_pos || !a.Kpool || !a.Vpool || a.pt_ld > 64 || a.n_split != 1 || (!a.q_partial && (!a.Knew || !a.Vnew))) return -1;
+        if (!a.d_pos || !a.Kpool || !a.Vpool || a.pt_ld > 448 || (a.page_size != 1 && a.page_size != KV_PAGE) || a.n_split != 1 || (!a.q_partial && (!a.Knew || !a.Vnew))) return -1;
         static const int nwh = getenv("WX_SELF_NWH") ? atoi(getenv("WX_SELF_NWH")) : 2;
         dim3 grid((a.B * a.H + 3) / 4);
         if (a.dt == DT_BF16) {
@@ -465,14 +488,21 @@ int launch_attn_decode(const AttnArgs& a, hipStream_t st) {
     }
     if (!a.K || !a.V || a.n_keys <= 0) return -1;
     if (a.n_split > 1 && !a.partial) return -1;
-    dim3 grid(a.B * a.H, a.n_split), block(256);
-    if (a.dt == DT_BF16) {
-        hipLaunchKernelGGL(attn_decode_kernel<bf16>, grid, block, 0, st, a);
-        if (a.n_split > 1) hipLaunchKernelGGL(attn_decode_combine_kernel<bf16>, dim3(a.B * a.H), dim3(64), 0, st, a);
-    } else {
-        hipLaunchKernelGGL(attn_decode_kernel<float>, grid, block, 0, st, a);
-        if (a.n_split > 1) hipLaunchKernelGGL(attn_decode_combine_kernel<float>, dim3(a.B * a.H), dim3(64), 0, st, a);
-    }
+    if (a.kv_group < 1 || a.kv_group > 8) return -1;
+    const int n_kv = (a.B + a.kv_group - 1) / a.kv_group;
+    dim3 grid(n_kv * a.H, a.n_split), block(256);
+    const int nq = a.kv_group == 1 ? 1 : a.kv_group == 2 ? 2 : a.kv_group <= 4 ? 4 : a.kv_group == 5 ? 5 : 8;
+#define WX_LAUNCH_CROSS(T)                                                                                      \
+    switch (nq) {                                                                                               \
+        case 1: hipLaunchKernelGGL((attn_decode_kernel<T, 1>), grid, block, 0, st, a); break;                   \
+        case 2: hipLaunchKernelGGL((attn_decode_kernel<T, 2>), grid, block, 0, st, a); break;                   \
+        case 4: hipLaunchKernelGGL((attn_decode_kernel<T, 4>), grid, block, 0, st, a); break;                   \
+        case 5: hipLaunchKernelGGL((attn_decode_kernel<T, 5>), grid, block, 0, st, a); break;                   \
+        default: hipLaunchKernelGGL((attn_decode_kernel<T, 8>), grid, block, 0, st, a); break;                  \
+    }                                                                                                           \
+    if (a.n_split > 1) hipLaunchKernelGGL(attn_decode_combine_kernel<T>, dim3(a.B * a.H), dim3(64), 0, st, a);
+    if (a.dt == DT_BF16) { WX_LAUNCH_CROSS(bf16) } else { WX_LAUNCH_CROSS(float) }
+#undef WX_LAUNCH_CROSS
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -115,8 +115,13 @@ struct AttnArgs {
     // dense keys/values: K + (b*H + h)*kv_sbh + t*64
     const void* K = nullptr; const void* V = nullptr; int64_t kv_sbh = 0;
     int n_keys = 0;                      // dense key count (ignored when d_pos != nullptr)
-    // paged self-attention cache (decoder): page_table[b*pt_ld + t/KV_PAGE] -> page p; row at ((p*H + h)*KV_PAGE + t%KV_PAGE)*64
-    const int32_t* page_table = nullptr; int pt_ld = 0;
+    // paged self-attention cache (decoder): page_table[b*pt_ld + t/PS] -> page p; row at ((p*H + h)*PS + t%PS)*64 with
+    // PS = page_size: KV_PAGE (16) for greedy decoding; 1 for beam search, where a sequence's cache is the list of
+    // token nodes on its path through the beam tree (reordering beams = gathering index rows, no K/V is ever copied)
+    const int32_t* page_table = nullptr; int pt_ld = 0; int page_size = KV_PAGE;
+    // cross-attention: kv_group consecutive query rows (the beams of one window) share one K/V entry: row b reads the
+    // cache of window b / kv_group, and one workgroup streams it once for the whole group
+    int kv_group = 1;
     void* Kpool = nullptr; void* Vpool = nullptr;   // written at position *d_pos with the new token's k/v
     const void* Knew = nullptr; const void* Vnew = nullptr; int64_t new_sb = 0;  // k/v of the current token: + b*new_sb + h*64
     const int32_t* d_pos = nullptr;      // device scalar: current position t (keys 0..t are attended)
@@ -147,5 +152,22 @@ struct SamplerArgs {
 int launch_sampler(const SamplerArgs& s, hipStream_t st);
 int launch_finish_tokens(int32_t* tokens, int ld_tok, int n_prompt, int tok_eot, const int32_t* d_pos, int32_t* n_tokens,
                          int B, hipStream_t st);
+
+// ---- beam search ----------------------------------------------------------------------------------------
+struct BeamArgs {
+    const float* logits = nullptr; int64_t ldl = 0; int n_vocab = 0;
+    int32_t* tokens = nullptr; int32_t* tokens_tmp = nullptr; int ld_tok = 0;   // [R][n_text_ctx]
+    int32_t* node = nullptr; int32_t* node_tmp = nullptr;                       // [R][n_text_ctx] KV node of every position
+    float* sum_logprob = nullptr; float* sum_tmp = nullptr;                     // [R]
+    float* cand_score = nullptr; int32_t* cand_tok = nullptr;                   // [R][9] proposals, best first
+    int32_t* src = nullptr; int32_t* next_tok = nullptr;                        // [R]
+    int32_t* fin_tokens = nullptr; float* fin_score = nullptr; int32_t* fin_count = nullptr;   // [B][max_candidates][ctx], [B][mc], [B]
+    int32_t* d_pos = nullptr; int32_t* d_counter = nullptr; int32_t* n_complete = nullptr;
+    const uint8_t* suppress = nullptr; float* no_speech = nullptr;              // no_speech: [B]
+    int B = 0, n = 0, max_candidates = 0, n_prompt = 0, sot_index = 0;
+    int tok_eot = 0, tok_blank = 0, tok_no_speech = 0, tok_no_timestamps = 0, tok_timestamp_begin = 0;
+    int without_timestamps = 1, suppress_blank = 1, max_initial_ts = 50;
+};
+int launch_beam_step(const BeamArgs& s, hipStream_t st);   // topk -> select -> gather -> commit (position += 1)
 
 }  // namespace wx

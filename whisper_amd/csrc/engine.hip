@@ -80,6 +80,11 @@ struct wx_engine {
     float *sum_logprob = nullptr, *no_speech = nullptr, *partial = nullptr, *gpartial = nullptr;
     int32_t* h_pinned = nullptr;
     int encoded_B = 0;
+    // beam search state (rows = windows x beams <= max_batch)
+    int beam_n = 0;                      // > 0 while a beam decode is building / replaying its step
+    int32_t *b_tokens_tmp = nullptr, *b_node = nullptr, *b_node_tmp = nullptr, *b_cand_tok = nullptr, *b_src = nullptr, *b_next = nullptr;
+    int32_t *b_fin_tokens = nullptr, *b_fin_count = nullptr;
+    float *b_sum_tmp = nullptr, *b_cand_score = nullptr, *b_fin_score = nullptr;
 
     hipStream_t own_stream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
@@ -428,6 +433,20 @@ int wx_finalize(wx_engine* e) {
     if ((r = A((void**)&e->no_speech, (size_t)B * 4))) return r;
     if ((r = A((void**)&e->partial, (size_t)B * e->Ht * 8 * (HEAD_DIM + 2) * 4))) return r;
     if ((r = A((void**)&e->gpartial, (size_t)16 * B * 3 * d * 4))) return r;   // split-K partial tiles of the decode GEMMs
+    {   // beam search
+        const size_t ctx = c.n_text_ctx;
+        if ((r = A((void**)&e->b_tokens_tmp, (size_t)B * ctx * 4))) return r;
+        if ((r = A((void**)&e->b_node, (size_t)B * ctx * 4))) return r;
+        if ((r = A((void**)&e->b_node_tmp, (size_t)B * ctx * 4))) return r;
+        if ((r = A((void**)&e->b_cand_tok, (size_t)B * 9 * 4))) return r;
+        if ((r = A((void**)&e->b_cand_score, (size_t)B * 9 * 4))) return r;
+        if ((r = A((void**)&e->b_src, (size_t)B * 4))) return r;
+        if ((r = A((void**)&e->b_next, (size_t)B * 4))) return r;
+        if ((r = A((void**)&e->b_sum_tmp, (size_t)B * 4))) return r;
+        if ((r = A((void**)&e->b_fin_tokens, (size_t)2 * B * ctx * 4))) return r;
+        if ((r = A((void**)&e->b_fin_score, (size_t)2 * B * 4))) return r;
+        if ((r = A((void**)&e->b_fin_count, (size_t)B * 4))) return r;
+    }
     HIP_TRY(hipHostMalloc((void**)&e->h_pinned, 64));
     HIP_TRY(hipDeviceSynchronize());
     e->finalized = true;
@@ -556,9 +575,16 @@ int wx_get_encoder_output(wx_engine* e, int32_t B, float* d_out, void* stream) {
     return WX_OK;
 }
 
+// self-attention cache addressing for rows b0..: greedy = pages of 16 positions owned by the sequence; beam search = one
+// node per token, listed per row in e->b_node (following the beams gathers index rows, never K/V)
+static void set_self_cache(const wx_engine* e, AttnArgs& a, int b0) {
+    if (e->beam_n > 0) { a.page_table = e->b_node + (size_t)b0 * e->cfg.n_text_ctx; a.pt_ld = e->cfg.n_text_ctx; a.page_size = 1; }
+    else { a.page_table = e->page_table + (size_t)b0 * e->n_pages_seq; a.pt_ld = e->n_pages_seq; a.page_size = KV_PAGE; }
+}
+
 // one decoder step for position *d_pos (all launches read the position from device memory -> graph-replayable)
 // fp32 ("token-exact") sequence: every GEMM applies its own epilogue, LayerNorm is a separate kernel.
-static int decode_step_f32(wx_engine* e, int B, const SamplerArgs& sa, hipStream_t st) {
+static int decode_step_f32(wx_engine* e, int B, const SamplerArgs* sa, hipStream_t st) {
     const int d = e->d, dtp = e->dt, T = e->T;
     const size_t es = dtype_size(dtp);
     const wx_config& c = e->cfg;
@@ -566,7 +592,7 @@ static int decode_step_f32(wx_engine* e, int B, const SamplerArgs& sa, hipStream
     const size_t cross_layer = (size_t)c.max_batch * e->Ht * T * HEAD_DIM;
     const size_t self_layer = (size_t)c.max_batch * e->n_pages_seq * e->Ht * KV_PAGE * HEAD_DIM;
     int n_split = 1;
-    while (n_split < 6 && B * e->Ht * n_split < 512) ++n_split;
+    while (n_split < 6 && (B / (e->beam_n > 0 ? e->beam_n : 1)) * e->Ht * n_split < 512) ++n_split;
     for (int i = 0; i < c.n_text_layer; ++i) {
         const LayerW& L = e->dec[i];
         WX_TRY(launch_layernorm(e->dx, L.ln1_g, L.ln1_b, e->dxn, dtp, B, d, st));
@@ -579,7 +605,7 @@ static int decode_step_f32(wx_engine* e, int B, const SamplerArgs& sa, hipStream
         {
             AttnArgs a;
             a.dt = dtp; a.Q = e->dqkv; a.q_sb = 3 * d; a.n_q = 1;
-            a.page_table = e->page_table; a.pt_ld = e->n_pages_seq;
+            set_self_cache(e, a, 0);
             a.Kpool = (char*)e->selfK + self_layer * i * es; a.Vpool = (char*)e->selfV + self_layer * i * es;
             a.Knew = (char*)e->dqkv + (size_t)d * es; a.Vnew = (char*)e->dqkv + (size_t)2 * d * es; a.new_sb = 3 * d;
             a.d_pos = e->d_pos; a.O = e->datt; a.o_sb = d; a.B = B; a.H = e->Ht; a.n_split = 1;
@@ -601,7 +627,7 @@ static int decode_step_f32(wx_engine* e, int B, const SamplerArgs& sa, hipStream
             AttnArgs a;
             a.dt = dtp; a.Q = e->dq; a.q_sb = d; a.n_q = 1;
             a.K = (char*)e->crossK + cross_layer * i * es; a.V = (char*)e->crossV + cross_layer * i * es;
-            a.kv_sbh = (int64_t)T * HEAD_DIM; a.n_keys = T;
+            a.kv_sbh = (int64_t)T * HEAD_DIM; a.n_keys = T; a.kv_group = e->beam_n > 0 ? e->beam_n : 1;
             a.O = e->datt; a.o_sb = d; a.B = B; a.H = e->Ht; a.n_split = n_split; a.partial = e->partial;
             const bool prof = e->prof_on && e->prof_used + 2 <= e->prof_events.size();
             if (prof) HIP_TRY(hipEventRecord(e->prof_events[e->prof_used], st));
@@ -631,7 +657,7 @@ static int decode_step_f32(wx_engine* e, int B, const SamplerArgs& sa, hipStream
         g.ep.out = e->logits; g.ep.out_dtype = DT_F32; g.ep.ldo = e->vocab_pad;
         WX_TRY(launch_gemm(g, st));
     }
-    WX_TRY(launch_sampler(sa, st));
+    if (sa) WX_TRY(launch_sampler(*sa, st));
     return 0;
 }
 
@@ -651,7 +677,7 @@ static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, floa
     const size_t cross_layer = (size_t)c.max_batch * e->Ht * T * HEAD_DIM, cross_b0 = (size_t)b0 * e->Ht * T * HEAD_DIM;
     const size_t self_layer = (size_t)c.max_batch * e->n_pages_seq * e->Ht * KV_PAGE * HEAD_DIM;
     int n_split = 1;
-    while (n_split < 6 && B * e->Ht * n_split < 512) ++n_split;
+    while (n_split < 6 && (B / (e->beam_n > 0 ? e->beam_n : 1)) * e->Ht * n_split < 512) ++n_split;
     const int s_dd = decode_gemm_split(d, d), s_fc2 = decode_gemm_split(d, 4 * d), s_qkv = decode_gemm_split(3 * d, d),
               s_fc1 = decode_gemm_split(4 * d, d);
     int pend_split = 0; const float* pend_bias = nullptr;       // residual update not yet folded into dx
@@ -673,7 +699,7 @@ static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, floa
         {
             AttnArgs a;
             a.dt = dtp; a.q_partial = gpartial; a.q_bias = L.self.bqkv; a.q_nsplit = s_qkv; a.q_scale = e->qk_scale; a.q_sb = 3 * d; a.n_q = 1;
-            a.page_table = e->page_table + (size_t)b0 * e->n_pages_seq; a.pt_ld = e->n_pages_seq;
+            set_self_cache(e, a, b0);
             a.Kpool = (char*)e->selfK + self_layer * i * es; a.Vpool = (char*)e->selfV + self_layer * i * es;
             a.d_pos = e->d_pos; a.O = datt; a.o_sb = d; a.B = B; a.H = e->Ht; a.n_split = 1;
             WX_TRY(launch_attn_decode(a, st));
@@ -685,7 +711,7 @@ static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, floa
             AttnArgs a;
             a.dt = dtp; a.q_partial = gpartial; a.q_bias = L.xbq; a.q_nsplit = s_dd; a.q_scale = e->qk_scale; a.q_sb = d; a.n_q = 1;
             a.K = (char*)e->crossK + (cross_layer * i + cross_b0) * es; a.V = (char*)e->crossV + (cross_layer * i + cross_b0) * es;
-            a.kv_sbh = (int64_t)T * HEAD_DIM; a.n_keys = T;
+            a.kv_sbh = (int64_t)T * HEAD_DIM; a.n_keys = T; a.kv_group = e->beam_n > 0 ? e->beam_n : 1;
             a.O = datt; a.o_sb = d; a.B = B; a.H = e->Ht; a.n_split = n_split; a.partial = apartial;
             const bool prof = prof_ok && e->prof_on && e->prof_used + 2 <= e->prof_events.size();
             if (prof) HIP_TRY(hipEventRecord(e->prof_events[e->prof_used], st));
@@ -713,14 +739,15 @@ static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, floa
     return 0;
 }
 
-static int decode_step_bf16(wx_engine* e, int B, const SamplerArgs& sa, hipStream_t st) {
+static int decode_step_bf16(wx_engine* e, int B, const SamplerArgs* sa, hipStream_t st) {
     int r = decode_layers_bf16(e, 0, B, e->gpartial, e->partial, true, st);
     if (r) return r;
-    WX_TRY(launch_sampler(sa, st));
+    if (sa) WX_TRY(launch_sampler(*sa, st));
     return 0;
 }
 
-static int decode_step(wx_engine* e, int B, const SamplerArgs& sa, hipStream_t st) {
+// decoder layers for B rows at position *d_pos, then the greedy sampler (sa) or nothing (the beam step follows)
+static int decode_step(wx_engine* e, int B, const SamplerArgs* sa, hipStream_t st) {
     return (e->dt == DT_BF16 && B <= 64) ? decode_step_bf16(e, B, sa, st) : decode_step_f32(e, B, sa, st);
 }
 
@@ -744,6 +771,7 @@ int wx_decode_greedy(wx_engine* e, int32_t B, const int32_t* h_prompt, const wx_
     if (!h_prompt || !opts || !d_tokens || !d_n_tokens || !d_sum_logprob || !d_no_speech_prob) return fail(WX_ERR_INVALID, "null argument");
     if (B <= 0 || B > e->encoded_B) return fail(WX_ERR_INVALID, "decode batch exceeds the last wx_encode batch");
     const wx_config& c = e->cfg;
+    e->beam_n = 0;
     wx_decode_opts o = *opts;
     if (o.n_prompt <= 0 || o.n_prompt >= c.n_text_ctx || o.sot_index < 0 || o.sot_index >= o.n_prompt)
         return fail(WX_ERR_INVALID, "bad prompt length / sot index");
@@ -779,11 +807,11 @@ int wx_decode_greedy(wx_engine* e, int32_t B, const int32_t* h_prompt, const wx_
         return 0;
     };
     if (o.use_graph) {
-        std::vector<int> key = {B, o.n_prompt, o.sot_index, o.without_timestamps, o.suppress_blank, o.max_initial_timestamp_index};
+        std::vector<int> key = {0, B, o.n_prompt, o.sot_index, o.without_timestamps, o.suppress_blank, o.max_initial_timestamp_index};
         if (!e->graph_exec || e->graph_key != key) {
             if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
             e->graph_key.clear();
-            int r = capture(st, [&] { return decode_step(e, B, sa, st); }, &e->graph_exec);
+            int r = capture(st, [&] { return decode_step(e, B, &sa, st); }, &e->graph_exec);
             if (r) return r;
             e->graph_key = key;
         }
@@ -799,7 +827,7 @@ int wx_decode_greedy(wx_engine* e, int32_t B, const int32_t* h_prompt, const wx_
     for (int s = 0; s < total_steps; ++s) {
         e->prof_on = want_prof && s >= o.n_prompt - 1 && ((s - (o.n_prompt - 1)) % o.profile_stride == 0);
         if (exec) HIP_TRY(hipGraphLaunch(exec, st));
-        else { int r = decode_step(e, B, sa, st); e->prof_on = false; if (r) return r; }
+        else { int r = decode_step(e, B, &sa, st); e->prof_on = false; if (r) return r; }
         if (s >= o.n_prompt - 1) {
             ++sampled;
             if (sampled % o.check_interval == 0 && s + 1 < total_steps) {
@@ -826,6 +854,105 @@ int wx_decode_greedy(wx_engine* e, int32_t B, const int32_t* h_prompt, const wx_
     return WX_OK;
 }
 
+int wx_decode_beam(wx_engine* e, int32_t B, int32_t beam_size, float patience, const int32_t* h_prompt, const wx_decode_opts* opts,
+                   int32_t* d_fin_tokens, float* d_fin_sum_logprob, int32_t* d_fin_count, int32_t* d_beam_tokens,
+                   float* d_beam_sum_logprob, float* d_no_speech_prob, int32_t* h_steps, void* stream) {
+    if (!e || !e->finalized) return fail(WX_ERR_STATE, "engine not finalized");
+    if (!h_prompt || !opts || !d_fin_tokens || !d_fin_sum_logprob || !d_fin_count || !d_beam_tokens || !d_beam_sum_logprob || !d_no_speech_prob)
+        return fail(WX_ERR_INVALID, "null argument");
+    const wx_config& c = e->cfg;
+    if (beam_size < 1 || beam_size > 8) return fail(WX_ERR_INVALID, "beam_size must be 1..8");
+    if (!(patience >= 1.0f) || patience > 2.0f) return fail(WX_ERR_INVALID, "patience must be in [1, 2]");
+    const int n = beam_size, R = B * n, maxc = (int)lroundf(n * patience);
+    if (B <= 0 || B > e->encoded_B) return fail(WX_ERR_INVALID, "decode batch exceeds the last wx_encode batch");
+    if (R > c.max_batch) return fail(WX_ERR_INVALID, "windows x beam_size exceeds max_batch");
+    wx_decode_opts o = *opts;
+    if (o.n_prompt <= 0 || o.n_prompt >= c.n_text_ctx || o.sot_index < 0 || o.sot_index >= o.n_prompt)
+        return fail(WX_ERR_INVALID, "bad prompt length / sot index");
+    for (int i = 0; i < o.n_prompt; ++i) if (h_prompt[i] < 0 || h_prompt[i] >= c.n_vocab) return fail(WX_ERR_INVALID, "prompt id out of range");
+    int sample_len = o.max_new_tokens > 0 ? o.max_new_tokens : c.n_text_ctx / 2;
+    if (o.n_prompt + sample_len > c.n_text_ctx) sample_len = c.n_text_ctx - o.n_prompt;
+    if (o.check_interval < 1) o.check_interval = 8;
+    StreamScope sc(e, stream);
+    hipStream_t st = sc.st;
+    e->beam_n = n;
+    {
+        std::vector<int32_t> rows((size_t)R * c.n_text_ctx, c.tok_eot), node((size_t)R * c.n_text_ctx, 0);
+        for (int r = 0; r < R; ++r) { memcpy(&rows[(size_t)r * c.n_text_ctx], h_prompt, (size_t)o.n_prompt * 4); node[(size_t)r * c.n_text_ctx] = r; }
+        HIP_TRY(hipMemcpyAsync(e->tokens, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(e->b_node, node.data(), node.size() * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(e->d_pos, 0, 64, st));
+        HIP_TRY(hipMemsetAsync(e->sum_logprob, 0, (size_t)R * 4, st));
+        HIP_TRY(hipMemsetAsync(e->no_speech, 0, (size_t)B * 4, st));
+        HIP_TRY(hipMemsetAsync(e->b_fin_count, 0, (size_t)B * 4, st));
+        HIP_TRY(hipMemsetAsync(e->b_fin_score, 0, (size_t)B * maxc * 4, st));
+        std::vector<int32_t> fin((size_t)B * maxc * c.n_text_ctx, c.tok_eot);
+        HIP_TRY(hipMemcpyAsync(e->b_fin_tokens, fin.data(), fin.size() * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    BeamArgs ba;
+    ba.logits = e->logits; ba.ldl = e->vocab_pad; ba.n_vocab = c.n_vocab;
+    ba.tokens = e->tokens; ba.tokens_tmp = e->b_tokens_tmp; ba.ld_tok = c.n_text_ctx;
+    ba.node = e->b_node; ba.node_tmp = e->b_node_tmp;
+    ba.sum_logprob = e->sum_logprob; ba.sum_tmp = e->b_sum_tmp;
+    ba.cand_score = e->b_cand_score; ba.cand_tok = e->b_cand_tok; ba.src = e->b_src; ba.next_tok = e->b_next;
+    ba.fin_tokens = e->b_fin_tokens; ba.fin_score = e->b_fin_score; ba.fin_count = e->b_fin_count;
+    ba.d_pos = e->d_pos; ba.d_counter = e->d_counter; ba.n_complete = e->n_finished;
+    ba.suppress = e->suppress; ba.no_speech = e->no_speech;
+    ba.B = B; ba.n = n; ba.max_candidates = maxc; ba.n_prompt = o.n_prompt; ba.sot_index = o.sot_index;
+    ba.tok_eot = c.tok_eot; ba.tok_blank = c.tok_blank; ba.tok_no_speech = c.tok_no_speech;
+    ba.tok_no_timestamps = c.tok_no_timestamps; ba.tok_timestamp_begin = c.tok_timestamp_begin;
+    ba.without_timestamps = o.without_timestamps; ba.suppress_blank = o.suppress_blank; ba.max_initial_ts = o.max_initial_timestamp_index;
+    auto step = [&]() -> int {
+        int r = decode_step(e, R, nullptr, st);
+        if (r) return r;
+        WX_TRY(launch_beam_step(ba, st));
+        return 0;
+    };
+    const int total_steps = o.n_prompt - 1 + sample_len;
+    hipGraphExec_t exec = nullptr;
+    if (o.use_graph) {
+        std::vector<int> key = {n, B, o.n_prompt, o.sot_index, o.without_timestamps, o.suppress_blank, o.max_initial_timestamp_index, maxc};
+        if (!e->graph_exec || e->graph_key != key) {
+            if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
+            e->graph_key.clear();
+            hipGraph_t graph = nullptr;
+            HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+            int r = step();
+            hipError_t ce = hipStreamEndCapture(st, &graph);
+            if (r != 0) { if (graph) (void)hipGraphDestroy(graph); return r; }
+            if (ce != hipSuccess) return fail(WX_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+            hipError_t ie = hipGraphInstantiate(&e->graph_exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ie != hipSuccess) { e->graph_exec = nullptr; return fail(WX_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
+            e->graph_key = key;
+        }
+        exec = e->graph_exec;
+    }
+    int sampled = 0;
+    for (int s = 0; s < total_steps; ++s) {
+        if (exec) HIP_TRY(hipGraphLaunch(exec, st));
+        else { int r = step(); if (r) return r; }
+        if (s >= o.n_prompt - 1) {
+            ++sampled;
+            if (sampled % o.check_interval == 0 && s + 1 < total_steps) {
+                HIP_TRY(hipMemcpyAsync(e->h_pinned, e->n_finished, 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                if (e->h_pinned[0] >= B) break;          // every window has max_candidates finished sequences
+            }
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(d_fin_tokens, e->b_fin_tokens, (size_t)B * maxc * c.n_text_ctx * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_fin_sum_logprob, e->b_fin_score, (size_t)B * maxc * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_fin_count, e->b_fin_count, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_beam_tokens, e->tokens, (size_t)R * c.n_text_ctx * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_beam_sum_logprob, e->sum_logprob, (size_t)R * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_no_speech_prob, e->no_speech, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+    if (h_steps) *h_steps = sampled;
+    e->beam_n = 0;
+    return WX_OK;
+}
+
 int wx_get_profile(wx_engine* e, double* total_ms, int64_t* launches) {
     if (!e || !total_ms || !launches) return fail(WX_ERR_INVALID, "null argument");
     *total_ms = e->prof_ms; *launches = e->prof_launches;
@@ -837,6 +964,7 @@ int wx_decoder_logits(wx_engine* e, int32_t B, const int32_t* d_tokens, int32_t 
     if (!d_tokens || !d_logits || n <= 0 || n > e->cfg.n_text_ctx) return fail(WX_ERR_INVALID, "bad argument");
     if (B <= 0 || B > e->encoded_B) return fail(WX_ERR_INVALID, "batch exceeds the last wx_encode batch");
     const wx_config& c = e->cfg;
+    e->beam_n = 0;
     StreamScope sc(e, stream);
     hipStream_t st = sc.st;
     HIP_TRY(hipMemcpy2DAsync(e->tokens, (size_t)c.n_text_ctx * 4, d_tokens, (size_t)n * 4, (size_t)n * 4, B, hipMemcpyDeviceToDevice, st));
@@ -846,7 +974,7 @@ int wx_decoder_logits(wx_engine* e, int32_t B, const int32_t* d_tokens, int32_t 
     SamplerArgs sa = make_sampler(e, B, o, 1);
     sa.no_speech = nullptr;
     for (int t = 0; t < n; ++t) {
-        int r = decode_step(e, B, sa, st);
+        int r = decode_step(e, B, &sa, st);
         if (r) return r;
         HIP_TRY(hipMemcpy2DAsync(d_logits + (size_t)t * c.n_vocab, (size_t)n * c.n_vocab * 4, e->logits, (size_t)e->vocab_pad * 4,
                                  (size_t)c.n_vocab * 4, B, hipMemcpyDeviceToDevice, st));

@@ -178,6 +178,56 @@ class WhisperEngine:
         return {"tokens": tokens, "n_tokens": n_tokens, "sum_logprobs": sum_lp, "no_speech_probs": nsp,
                 "steps": int(steps.value), "n_prompt": len(prompt)}
 
+    def decode_beam(self, B: int, prompt: Sequence[int], beam_size: int = 5, patience: float = 1.0, max_new_tokens: int = 0,
+                    without_timestamps: bool = True, suppress_blank: bool = True, max_initial_timestamp_index: int = 50,
+                    use_graph: bool = True, check_interval: int = 8) -> Dict[str, object]:
+        """Beam search for the B windows of the last encode (upstream ``DecodingTask.run`` with ``beam_size``).  The device
+        runs the per-step update; ``finalize`` (short finished lists are topped up with the live beams, best first) and
+        the ``sum_logprob / length`` ranking run here on the few candidates that come back."""
+        prompt = [int(p) for p in prompt]
+        opts = _lib.WxDecodeOpts(
+            n_prompt=len(prompt), sot_index=prompt.index(self.tok.sot), max_new_tokens=int(max_new_tokens),
+            without_timestamps=int(without_timestamps), suppress_blank=int(suppress_blank),
+            max_initial_timestamp_index=int(max_initial_timestamp_index), use_graph=int(use_graph),
+            check_interval=int(check_interval), profile_stride=0)
+        dev, n, ctx = self.torch_device, int(beam_size), self.dims.n_text_ctx
+        maxc = int(round(n * patience))
+        fin_t = torch.empty((B, maxc, ctx), dtype=torch.int32, device=dev)
+        fin_s = torch.empty((B, maxc), dtype=torch.float32, device=dev)
+        fin_c = torch.empty(B, dtype=torch.int32, device=dev)
+        beam_t = torch.empty((B * n, ctx), dtype=torch.int32, device=dev)
+        beam_s = torch.empty(B * n, dtype=torch.float32, device=dev)
+        nsp = torch.empty(B, dtype=torch.float32, device=dev)
+        steps = ctypes.c_int32(0)
+        h_prompt = (ctypes.c_int32 * len(prompt))(*prompt)
+        _lib.check(self.lib.wx_decode_beam(self.handle, B, n, ctypes.c_float(patience), h_prompt, ctypes.byref(opts), _ptr(fin_t),
+                                           _ptr(fin_s), _ptr(fin_c), _ptr(beam_t), _ptr(beam_s), _ptr(nsp), ctypes.byref(steps),
+                                           self._stream()), "wx_decode_beam")
+        fin_t, fin_s, fin_c = fin_t.cpu().numpy(), fin_s.cpu().numpy(), fin_c.cpu().numpy()
+        beam_t, beam_s = beam_t.cpu().numpy().reshape(B, n, ctx), beam_s.cpu().numpy().reshape(B, n)
+        eot, n_prompt = self.tok.eot, len(prompt)
+
+        def body(row):
+            seq = row[n_prompt:].tolist()
+            return seq[:seq.index(eot)] if eot in seq else seq
+        live_len = n_prompt + int(steps.value)          # tokens every live beam holds (prompt + one per sampling step)
+        tokens, sums, cands = [], [], []
+        for b in range(B):
+            seqs: Dict[tuple, float] = {}
+            for k in range(int(fin_c[b])):
+                seqs[tuple(body(fin_t[b, k]))] = float(fin_s[b, k])
+            if len(seqs) < n:                             # finalize(): not enough finished sequences
+                for j in list(np.argsort(beam_s[b]))[::-1]:
+                    seq = beam_t[b, j, n_prompt:live_len].tolist()
+                    seqs[tuple(seq[:seq.index(eot)] if eot in seq else seq)] = float(beam_s[b, j])
+                    if len(seqs) >= n:
+                        break
+            items = list(seqs.items())
+            best = int(np.argmax([sc / len(sq) if len(sq) else -np.inf for sq, sc in items]))
+            tokens.append(list(items[best][0])); sums.append(items[best][1]); cands.append([(list(sq), sc) for sq, sc in items])
+        return {"tokens": tokens, "sum_logprobs": sums, "no_speech_probs": nsp.cpu().tolist(), "steps": int(steps.value),
+                "n_prompt": n_prompt, "candidates": cands}
+
     def last_profile(self):
         """(total_ms, launches) of the cross-attention launches bracketed by the last profiled eager decode."""
         ms, n = ctypes.c_double(0.0), ctypes.c_int64(0)
@@ -203,23 +253,31 @@ class WhisperEngine:
         return seq
 
     def transcribe_mel(self, mel: torch.Tensor, n_content_frames: int, window_lo: int, window_hi: int,
-                       prompt: Sequence[int], **decode_kw) -> Dict[str, object]:
-        """Decode windows [window_lo, window_hi) of a whole-file mel ``[n_mels, ld]`` in batches of ``max_batch``."""
+                       prompt: Sequence[int], beam_size: Optional[int] = None, patience: float = 1.0, **decode_kw) -> Dict[str, object]:
+        """Decode windows [window_lo, window_hi) of a whole-file mel ``[n_mels, ld]`` in batches of ``max_batch`` windows
+        (greedy) or ``max_batch // beam_size`` windows (beam search: rows = windows x beams)."""
         toks: List[List[int]] = []
         sums: List[float] = []
         nsp: List[float] = []
         steps = 0
         ld = mel.stride(0)
-        for w0 in range(window_lo, window_hi, self.max_batch):
-            B = min(self.max_batch, window_hi - w0)
+        per = self.max_batch if not beam_size else max(1, self.max_batch // int(beam_size))
+        if beam_size and int(beam_size) > self.max_batch:
+            raise ValueError("beam_size exceeds max_batch")
+        for w0 in range(window_lo, window_hi, per):
+            B = min(per, window_hi - w0)
             view = mel[:, w0 * N_FRAMES:]
             self.encode(view, N_FRAMES, ld, n_content_frames - w0 * N_FRAMES, B)
-            r = self.decode_greedy(B, prompt, **decode_kw)
-            t_cpu, n_cpu = r["tokens"].cpu(), r["n_tokens"].cpu()
-            for b in range(B):
-                toks.append(t_cpu[b, r["n_prompt"]:r["n_prompt"] + int(n_cpu[b])].tolist())
-            sums += r["sum_logprobs"].cpu().tolist()
-            nsp += r["no_speech_probs"].cpu().tolist()
+            if beam_size:
+                r = self.decode_beam(B, prompt, beam_size=int(beam_size), patience=patience, **decode_kw)
+                toks += r["tokens"]; sums += r["sum_logprobs"]; nsp += r["no_speech_probs"]
+            else:
+                r = self.decode_greedy(B, prompt, **decode_kw)
+                t_cpu, n_cpu = r["tokens"].cpu(), r["n_tokens"].cpu()
+                for b in range(B):
+                    toks.append(t_cpu[b, r["n_prompt"]:r["n_prompt"] + int(n_cpu[b])].tolist())
+                sums += r["sum_logprobs"].cpu().tolist()
+                nsp += r["no_speech_probs"].cpu().tolist()
             steps += r["steps"]
         return {"tokens": toks, "sum_logprobs": sums, "no_speech_probs": nsp, "steps": steps}
 

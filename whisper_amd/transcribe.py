@@ -115,7 +115,10 @@ def _prompt_ids(prompt, tokenizer: Tokenizer) -> Optional[List[int]]:
 
 def transcribe(audio, language: Optional[str] = None, prompt: Union[None, str, Sequence[int]] = None,
                **decode_kw) -> Dict[str, object]:
-    """Returns ``{"text", "confidence", "chunks_processed"}`` plus ``language``, ``tokens`` (per window),
+    """``decode_kw``: ``beam_size`` (None = greedy, upstream's default for the reference's call), ``patience``,
+    ``max_new_tokens``, ``without_timestamps``.
+
+    Returns ``{"text", "confidence", "chunks_processed"}`` plus ``language``, ``tokens`` (per window),
     ``avg_logprob`` and ``no_speech_prob`` (per window).
 
     ``confidence``: in the default ``confidence_mode="reference"`` this is 0.0 — what the reference computes, because it
