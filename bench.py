@@ -44,8 +44,11 @@ def parse():
     p.add_argument("--batch", type=int, default=64, help="30 s windows per GPU per step")
     p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--max-new-tokens", type=int, default=0, help="0 = upstream sample_len (n_text_ctx // 2)")
+    p.add_argument("--beam", type=int, default=0, help="beam width (0 = greedy); rows = batch x beam must be <= 64 for the fast decode path")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real multi-GPU path) | gloo (rehearsal of the N>1 code path)")
+    p.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
     p.add_argument("--cpu-decode-steps", type=int, default=24)
     p.add_argument("--no-profile-pass", action="store_true", help="skip the event-bracketed eager pass (PMC runs)")
     return p.parse_args()
@@ -86,12 +89,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
 
+    from whisper_amd import dist as wdist
     from whisper_amd.dist import sharded_mel
     from whisper_amd.engine import WhisperEngine
 
@@ -99,7 +108,7 @@ def main():
     tok = ck.special_tokens_for(dims.n_vocab)
     B = args.batch
     sd = ck.synthetic_state_dict(dims, seed=0)
-    eng = WhisperEngine(dims, sd, precision=args.precision, max_batch=B, device=local_rank)
+    eng = WhisperEngine(dims, sd, precision=args.precision, max_batch=B * max(1, args.beam), device=local_rank)
     prompt = eng.initial_tokens(0)
 
     # this rank's windows of one long virtual file of world*B windows; clip i of the file uses seed i
@@ -116,13 +125,19 @@ def main():
     def step(use_graph=True, profile_stride=0):
         mel = sharded_mel(eng, pcm, s_lo, n_file, w_lo, w_hi)
         eng.encode(mel, N_FRAMES, mel.stride(0), n_file // 160 - w_lo * N_FRAMES, B)
-        r = eng.decode_greedy(B, prompt, max_new_tokens=args.max_new_tokens, use_graph=use_graph,
-                              profile_stride=profile_stride)
+        if args.beam:
+            rb = eng.decode_beam(B, prompt, beam_size=args.beam, max_new_tokens=args.max_new_tokens, use_graph=use_graph)
+            toks = torch.full((B, dims.n_text_ctx), eng.tok.eot, dtype=torch.int32)
+            for b, t in enumerate(rb["tokens"]):
+                toks[b, :len(t)] = torch.tensor(t, dtype=torch.int32)
+            r = {"tokens": toks.to(dev), "n_tokens": torch.tensor([len(t) for t in rb["tokens"]], dtype=torch.int32, device=dev),
+                 "steps": rb["steps"]}
+        else:
+            r = eng.decode_greedy(B, prompt, max_new_tokens=args.max_new_tokens, use_graph=use_graph,
+                                  profile_stride=profile_stride)
         if world > 1:      # result gather: padded ids + lengths, ~115 KB per rank
-            out = [torch.empty_like(r["tokens"]) for _ in range(world)]
-            dist.all_gather(out, r["tokens"])
-            lens = [torch.empty_like(r["n_tokens"]) for _ in range(world)]
-            dist.all_gather(lens, r["n_tokens"])
+            out = wdist.all_gather(r["tokens"])
+            lens = wdist.all_gather(r["n_tokens"])
         state["r"], state["mel"] = r, mel
         return r
 
@@ -146,14 +161,14 @@ def main():
 
         # dominant kernel: event-bracketed eager pass on the same batch
         prof_ms, prof_n = 0.0, 0
-        if not args.no_profile_pass:
+        if not args.no_profile_pass and not args.beam:
             step(use_graph=False, profile_stride=8)
             torch.cuda.synchronize(dev)
             prof_ms, prof_n = eng.last_profile()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wdist.all_reduce_max(t)
     elapsed = float(t.item())
 
     if rank == 0:
@@ -176,8 +191,9 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "config": {
-                "workload": f"Whisper {args.model} {args.precision} greedy, batch {B} x 30 s windows per GPU: log-mel + encoder + "
-                            f"cross-K/V + KV-cache decode (BASELINE.json configs[2])",
+                "workload": f"Whisper {args.model} {args.precision} {'beam=%d' % args.beam if args.beam else 'greedy'}, batch {B} x 30 s windows per GPU: "
+                            f"log-mel + encoder + cross-K/V + KV-cache decode"
+                            + (" (BASELINE.json configs[2])" if (args.model, args.beam, B) == ("large-v3", 0, 64) else ""),
                 "windows_per_gpu": B, "decode_steps_per_window": steps_per_window, "mean_new_tokens": n_tokens,
                 "prompt": "[sot, <|en|>, transcribe, notimestamps]", "weights": "seeded random init (no checkpoints offline)",
                 "hip_graph": not args.no_graph, "parallelism": f"window-dp{world}",

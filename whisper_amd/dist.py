@@ -27,6 +27,32 @@ def rank_world(group=None) -> Tuple[int, int]:
     return 0, 1
 
 
+def _host_staged(group=None) -> bool:
+    """gloo moves host memory: device tensors are staged through the host for it (RCCL takes them as they are)."""
+    return dist.get_backend(group) == "gloo"
+
+
+def all_reduce_max(t: torch.Tensor, group=None) -> None:
+    if t.is_cuda and _host_staged(group):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+
+
+def all_gather(t: torch.Tensor, group=None) -> List[torch.Tensor]:
+    world = dist.get_world_size(group)
+    if t.is_cuda and _host_staged(group):
+        h = t.cpu()
+        out = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(out, h, group=group)
+        return out
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t, group=group)
+    return out
+
+
 def local_sample_range(n_file: int, w_lo: int, w_hi: int) -> Tuple[int, int]:
     """File samples a rank needs for windows [w_lo, w_hi): its own span plus the STFT halo, clipped to the file."""
     lo = max(0, w_lo * N_SAMPLES - HALO)
@@ -45,7 +71,7 @@ def sharded_mel(engine, pcm_local: torch.Tensor, pcm_offset: int, n_file: int, w
     if n_frames > 0:
         engine.mel_stage1(pcm_local, pcm_offset, n_file, n_total, frame0, n_frames, mel, gmax)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)      # 4 bytes
+        all_reduce_max(gmax, group)      # 4 bytes
     if n_frames > 0:
         engine.mel_stage2(mel, n_frames, gmax)
     return mel
@@ -67,12 +93,7 @@ def gather_results(local: Dict[str, object], n_local_max: int, n_ctx: int, eot: 
     if world == 1:
         return {"tokens": toks, "sum_logprobs": list(local["sum_logprobs"]), "no_speech_probs": list(local["no_speech_probs"])}
     ids, lens, fl = ids.to(device), lens.to(device), fl.to(device)
-    g_ids = [torch.empty_like(ids) for _ in range(world)]
-    g_lens = [torch.empty_like(lens) for _ in range(world)]
-    g_fl = [torch.empty_like(fl) for _ in range(world)]
-    dist.all_gather(g_ids, ids, group=group)
-    dist.all_gather(g_lens, lens, group=group)
-    dist.all_gather(g_fl, fl, group=group)
+    g_ids, g_lens, g_fl = all_gather(ids, group), all_gather(lens, group), all_gather(fl, group)
     out_t, out_s, out_n = [], [], []
     for r in range(world):
         ic, lc, fc = g_ids[r].cpu(), g_lens[r].cpu(), g_fl[r].cpu()
