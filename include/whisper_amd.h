@@ -110,6 +110,19 @@ int wx_decode_greedy(wx_engine* e, int32_t B, const int32_t* h_prompt, const wx_
                      int32_t* d_tokens, int32_t* d_n_tokens, float* d_sum_logprob, float* d_no_speech_prob,
                      int32_t* h_steps, void* stream);
 
+/* wx_decode_greedy with a prompt PER WINDOW and an optional temperature: what upstream's sequential long-form loop needs
+ * (Whisper.transcribe inside ref:speech_recognition.py:55: every window is conditioned on the text decoded before it,
+ * "condition_on_previous_text", and re-decoded at temperatures 0.2 ... 1.0 when the compression-ratio / log-probability
+ * checks fail, "decode_with_fallback").  h_prompts [B][n_text_ctx] holds each row's initial ids (h_n_prompt[b] of them,
+ * <|startoftranscript|> at h_sot_index[b]); opts->n_prompt / sot_index are ignored.  Rows run in lockstep over positions,
+ * each starts sampling after its own prompt and stops at EOT, after max_new_tokens ids or at n_text_ctx.  temperature > 0
+ * samples from softmax(logits / T) with a counter-based generator seeded by `seed` (upstream draws from torch's global
+ * generator, so sampled ids agree with it in distribution only); log-probabilities are those of the unscaled logits, as
+ * upstream.  Outputs as wx_decode_greedy; d_n_tokens counts ids after each row's own prompt. */
+int wx_decode_rows(wx_engine* e, int32_t B, const int32_t* h_prompts, const int32_t* h_n_prompt, const int32_t* h_sot_index,
+                   const wx_decode_opts* opts, float temperature, uint32_t seed, int32_t* d_tokens, int32_t* d_n_tokens,
+                   float* d_sum_logprob, float* d_no_speech_prob, int32_t* h_steps, void* stream);
+
 /* replaces DecodingTask.run with BeamSearchDecoder (upstream beam_size / patience options; the reference itself never
  * sets them -- ref:speech_recognition.py:48-52 -- but BASELINE.json configs[3] does) for the B windows of the last
  * wx_encode.  Rows = B x beam_size must fit max_batch.  The device runs upstream's update() every step: per window the

@@ -43,6 +43,8 @@ PROTOTYPES = {
     "wx_encode": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "wx_get_encoder_output": (c_i32, [c_vp, c_i32, c_vp, c_vp]),
     "wx_decode_greedy": (c_i32, [c_vp, c_i32, c_vp, ctypes.POINTER(WxDecodeOpts), c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_i32), c_vp]),
+    "wx_decode_rows": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, ctypes.POINTER(WxDecodeOpts), ctypes.c_float, ctypes.c_uint32, c_vp, c_vp, c_vp,
+                               c_vp, ctypes.POINTER(c_i32), c_vp]),
     "wx_decode_beam": (c_i32, [c_vp, c_i32, c_i32, ctypes.c_float, c_vp, ctypes.POINTER(WxDecodeOpts), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                ctypes.POINTER(c_i32), c_vp]),
     "wx_decoder_logits": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp]),

@@ -144,14 +144,23 @@ struct SamplerArgs {
     const uint8_t* suppress = nullptr;             // [n_vocab] 1 = masked
     float* sum_logprob = nullptr; float* no_speech = nullptr;
     int32_t* n_finished = nullptr;                 // device counter of sequences that have emitted EOT
-    int B = 0, n_prompt = 0, sot_index = 0;
+    int B = 0, n_prompt = 0, sot_index = 0;        // prompt length / SOT position shared by all rows ...
+    const int32_t* row_n_prompt = nullptr;         // ... or per row (device arrays [B]): sequential long-form decoding
+    const int32_t* row_sot = nullptr;              //     carries a different amount of previous text into every window
+    int sample_len = 1 << 30;                      // per-row cap on sampled tokens (rows with short prompts stop first)
     int tok_eot = 0, tok_blank = 0, tok_no_speech = 0, tok_no_timestamps = 0, tok_timestamp_begin = 0;
     int without_timestamps = 1, suppress_blank = 1, max_initial_ts = 50;
     int forced = 0;                                // 1: teacher forcing, tokens are never written
+    float temperature = 0.f;                       // > 0: sample from softmax(logits / T) (Gumbel-max, counter-based RNG)
+    uint32_t seed = 0;
+    // when set, {temperature bits, seed, sample_len} are read from device memory instead, so a captured decode-step graph
+    // stays valid across calls that only change them (temperature fallback re-decodes the same window)
+    const uint32_t* dyn = nullptr;
 };
 int launch_sampler(const SamplerArgs& s, hipStream_t st);
-int launch_finish_tokens(int32_t* tokens, int ld_tok, int n_prompt, int tok_eot, const int32_t* d_pos, int32_t* n_tokens,
-                         int B, hipStream_t st);
+// n_tokens[b] = sampled ids before the first EOT; the tail of every row is EOT padded.  row_n_prompt may be null.
+int launch_finish_tokens(int32_t* tokens, int ld_tok, int n_prompt, const int32_t* row_n_prompt, int tok_eot, const int32_t* d_pos,
+                         int32_t* n_tokens, int B, hipStream_t st);
 
 // ---- beam search ----------------------------------------------------------------------------------------
 struct BeamArgs {

@@ -334,8 +334,29 @@ constexpr int SAMP_NT = 1024, SAMP_NW = SAMP_NT / 64;
 
 // One workgroup of 16 waves per sequence; ONE pass over the 200 KB logit row (16-B loads, suppress mask read 4 bytes at a
 // time, online max / sum-exp), because a CU sustains only ~25 GB/s of loads and a second pass would double the time.
+// candidate under selection: key = logit (temperature 0) or logit / T + Gumbel noise; raw = the unscaled logit
+struct Pick { float key; int i; float raw; };
+__device__ __forceinline__ Pick pick_better(Pick a, Pick b) {
+    if (b.key > a.key || (b.key == a.key && b.i < a.i)) return b;
+    return a;
+}
+__device__ __forceinline__ Pick wave_pick(Pick x) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        Pick y; y.key = __shfl_xor(x.key, off); y.i = __shfl_xor(x.i, off); y.raw = __shfl_xor(x.raw, off);
+        x = pick_better(x, y);
+    }
+    return x;
+}
+// counter-based uniform in (0, 1): one hash of (seed, row, position, token) per draw, no RNG state to carry
+__device__ __forceinline__ float uniform01(uint32_t seed, uint32_t row, uint32_t pos, uint32_t idx) {
+    uint32_t h = seed ^ (row * 0x9E3779B1u) ^ (pos * 0x85EBCA77u) ^ (idx * 0xC2B2AE3Du);
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+
 __global__ __launch_bounds__(SAMP_NT) void sampler_kernel(SamplerArgs s) {
-    __shared__ MaxIdx sh_all[SAMP_NW], sh_ts[SAMP_NW];
+    __shared__ Pick sh_all[SAMP_NW], sh_ts[SAMP_NW];
     __shared__ MS sh_msa[SAMP_NW], sh_mst[SAMP_NW];
     __shared__ float sh_f[SAMP_NW], sh_g[SAMP_NW];
     __shared__ int sh_flags[8];
@@ -343,8 +364,10 @@ __global__ __launch_bounds__(SAMP_NT) void sampler_kernel(SamplerArgs s) {
     const int t = *s.d_pos;
     const float* lg = s.logits + (int64_t)b * s.ldl;
     const int V = s.n_vocab;
+    const int n_prompt = s.row_n_prompt ? s.row_n_prompt[b] : s.n_prompt;
+    const int sot_index = s.row_sot ? s.row_sot[b] : s.sot_index;
 
-    if (t == s.sot_index && s.no_speech) {
+    if (t == sot_index && s.no_speech) {
         float mx = -INFINITY;
         for (int i = tid; i < V; i += SAMP_NT) mx = fmaxf(mx, lg[i]);
         mx = wave_max(mx);
@@ -365,22 +388,34 @@ __global__ __launch_bounds__(SAMP_NT) void sampler_kernel(SamplerArgs s) {
         __syncthreads();
     }
 
-    if (t >= s.n_prompt - 1 && !s.forced) {
+    if (t >= n_prompt - 1 && !s.forced && t + 1 < s.ld_tok) {
         int32_t* row = s.tokens + (int64_t)b * s.ld_tok;
         const int tb = s.tok_timestamp_begin;
-        const bool first_step = (t == s.n_prompt - 1);
+        const bool first_step = (t == n_prompt - 1);
+        const int cnt = t - n_prompt + 1;                            // sampled tokens so far
+        const float temperature = s.dyn ? __uint_as_float(s.dyn[0]) : s.temperature;
+        const uint32_t seed = s.dyn ? s.dyn[1] : s.seed;
+        const int sample_len = s.dyn ? (int)s.dyn[2] : s.sample_len;
+        int row_cap = s.ld_tok - n_prompt; if (row_cap > sample_len) row_cap = sample_len;
+        if (cnt >= row_cap) {
+            // upstream stops this window at sample_len / n_ctx: the row is closed with EOT (not counted, not scored)
+            if (tid == 0) {
+                const bool alive = row[t] != s.tok_eot;
+                row[t + 1] = s.tok_eot;
+                if (alive && cnt == row_cap) atomicAdd(s.n_finished, 1);
+            }
+        } else {
         if (tid == 0) {
             // timestamp-rule ranges (all empty in without_timestamps mode)
             int a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0, c_hi = 0, d_lo = V;
             if (!s.without_timestamps) {
-                const int cnt = t - s.n_prompt + 1;                 // sampled tokens so far
                 const bool last_ts = cnt >= 1 && row[t] >= tb;
                 const bool penult_ts = cnt < 2 || row[t - 1] >= tb;
                 if (last_ts) {
                     if (penult_ts) { a_lo = tb; a_hi = V; } else { a_lo = 0; a_hi = s.tok_eot; }
                 }
                 int ts_last = -1;
-                for (int j = t; j >= s.n_prompt; --j) if (row[j] >= tb) { ts_last = row[j]; break; }
+                for (int j = t; j >= n_prompt; --j) if (row[j] >= tb) { ts_last = row[j]; break; }
                 if (ts_last >= 0) { b_lo = tb; b_hi = (last_ts && !penult_ts) ? ts_last : ts_last + 1; }
                 if (first_step) {
                     c_hi = tb;                                      // [0, tb) masked
@@ -393,7 +428,9 @@ __global__ __launch_bounds__(SAMP_NT) void sampler_kernel(SamplerArgs s) {
         const int a_lo = sh_flags[0], a_hi = sh_flags[1], b_lo = sh_flags[2], b_hi = sh_flags[3], c_hi = sh_flags[4], d_lo = sh_flags[5];
         const bool ts_mode = !s.without_timestamps;
         const bool blank_rule = first_step && s.suppress_blank;
-        MaxIdx best_all{-INFINITY, 0x7fffffff}, best_ts{-INFINITY, 0x7fffffff};
+        const bool sampling = temperature > 0.f;
+        const float inv_t = sampling ? 1.0f / temperature : 1.0f;
+        Pick best_all{-INFINITY, 0x7fffffff, -INFINITY}, best_ts{-INFINITY, 0x7fffffff, -INFINITY};
         MS ms_all{-INFINITY, 0.f}, ms_ts{-INFINITY, 0.f};
         float max_text = -INFINITY;
         // suppress[] is padded to a multiple of 4 bytes (wx_finalize), logits rows to 16 floats
@@ -413,36 +450,39 @@ __global__ __launch_bounds__(SAMP_NT) void sampler_kernel(SamplerArgs s) {
                 }
                 if (m) continue;
                 const float v = v4[j];
-                best_all = better(best_all, MaxIdx{v, i});
+                float key = v;
+                if (sampling) key = v * inv_t - logf(-logf(uniform01(seed, b, t, i)));   // Gumbel-max
+                best_all = pick_better(best_all, Pick{key, i, v});
                 ms_add(ms_all, v);
-                if (i >= tb) { best_ts = better(best_ts, MaxIdx{v, i}); if (ts_mode) ms_add(ms_ts, v); }
+                if (i >= tb) { best_ts = pick_better(best_ts, Pick{key, i, v}); if (ts_mode) ms_add(ms_ts, v); }
                 else max_text = fmaxf(max_text, v);
             }
         }
-        best_all = wave_best(best_all); best_ts = wave_best(best_ts); max_text = wave_max(max_text);
+        best_all = wave_pick(best_all); best_ts = wave_pick(best_ts); max_text = wave_max(max_text);
         ms_all = wave_ms(ms_all); ms_ts = wave_ms(ms_ts);
         if (lane == 0) { sh_all[wid] = best_all; sh_ts[wid] = best_ts; sh_f[wid] = max_text; sh_msa[wid] = ms_all; sh_mst[wid] = ms_ts; }
         __syncthreads();
         if (tid == 0) {
             for (int w = 1; w < SAMP_NW; ++w) {
-                best_all = better(best_all, sh_all[w]); best_ts = better(best_ts, sh_ts[w]);
+                best_all = pick_better(best_all, sh_all[w]); best_ts = pick_better(best_ts, sh_ts[w]);
                 max_text = fmaxf(max_text, sh_f[w]);
                 ms_all = ms_merge(ms_all, sh_msa[w]); ms_ts = ms_merge(ms_ts, sh_mst[w]);
             }
-            // ms_*.m equals best_*.v (both are the maximum of the same set), so sum exp(v - max) = ms_*.s
+            // log-probabilities are always those of the UNSCALED filtered logits (upstream GreedyDecoder.update)
+            const float lse_all = ms_all.m + logf(ms_all.s);
             int chosen = best_all.i;
-            float logprob = -logf(ms_all.s);
-            if (ts_mode && best_ts.v > -INFINITY) {
-                const float lse_all = best_all.v + logf(ms_all.s);
-                const float ts_lp = best_ts.v + logf(ms_ts.s) - lse_all;
-                const float text_lp = max_text - lse_all;
-                if (ts_lp > text_lp) { chosen = best_ts.i; logprob = -logf(ms_ts.s); }
+            float logprob = best_all.raw - lse_all;
+            if (ts_mode && ms_ts.m > -INFINITY) {
+                const float lse_ts = ms_ts.m + logf(ms_ts.s);
+                const float ts_lp = lse_ts - lse_all, text_lp = max_text - lse_all;
+                if (ts_lp > text_lp) { chosen = best_ts.i; logprob = best_ts.raw - lse_ts; }   // only timestamps remain
             }
             const bool alive = row[t] != s.tok_eot;
             if (alive) s.sum_logprob[b] += logprob;
             const int next = alive ? chosen : s.tok_eot;
             row[t + 1] = next;
             if (alive && next == s.tok_eot) atomicAdd(s.n_finished, 1);
+        }
         }
     }
     __syncthreads();
@@ -459,9 +499,11 @@ int launch_sampler(const SamplerArgs& s, hipStream_t st) {
 }
 
 // After the loop: count sampled ids before the first EOT and pad the tail of every row with EOT.
-__global__ void finish_tokens_kernel(int32_t* tokens, int ld_tok, int n_prompt, int tok_eot, const int32_t* d_pos, int32_t* n_tokens) {
+__global__ void finish_tokens_kernel(int32_t* tokens, int ld_tok, int n_prompt_all, const int32_t* row_n_prompt, int tok_eot,
+                                     const int32_t* d_pos, int32_t* n_tokens) {
     const int b = blockIdx.x;
     if (threadIdx.x != 0) return;
+    const int n_prompt = row_n_prompt ? row_n_prompt[b] : n_prompt_all;
     int32_t* row = tokens + (int64_t)b * ld_tok;
     const int last = *d_pos;             // index of the last written token
     int n = 0;
@@ -471,9 +513,9 @@ __global__ void finish_tokens_kernel(int32_t* tokens, int ld_tok, int n_prompt, 
     }
     n_tokens[b] = n;
 }
-int launch_finish_tokens(int32_t* tokens, int ld_tok, int n_prompt, int tok_eot, const int32_t* d_pos, int32_t* n_tokens, int B,
-                         hipStream_t st) {
-    hipLaunchKernelGGL(finish_tokens_kernel, dim3(B), dim3(64), 0, st, tokens, ld_tok, n_prompt, tok_eot, d_pos, n_tokens);
+int launch_finish_tokens(int32_t* tokens, int ld_tok, int n_prompt, const int32_t* row_n_prompt, int tok_eot, const int32_t* d_pos,
+                         int32_t* n_tokens, int B, hipStream_t st) {
+    hipLaunchKernelGGL(finish_tokens_kernel, dim3(B), dim3(64), 0, st, tokens, ld_tok, n_prompt, row_n_prompt, tok_eot, d_pos, n_tokens);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

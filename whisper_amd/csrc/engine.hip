@@ -77,6 +77,8 @@ struct wx_engine {
     float* dx = nullptr; void *dxn = nullptr, *dqkv = nullptr, *datt = nullptr, *dhid = nullptr, *dq = nullptr;
     float* logits = nullptr;
     int32_t *tokens = nullptr, *d_pos = nullptr, *d_counter = nullptr, *n_finished = nullptr, *n_tokens = nullptr;
+    int32_t *row_n_prompt = nullptr, *row_sot = nullptr;      // per-row prompt length / SOT position
+    uint32_t* dyn = nullptr;                                 // {temperature bits, seed, sample_len} read by the sampler
     float *sum_logprob = nullptr, *no_speech = nullptr, *partial = nullptr, *gpartial = nullptr;
     int32_t* h_pinned = nullptr;
     int encoded_B = 0;
@@ -429,6 +431,9 @@ int wx_finalize(wx_engine* e) {
     e->d_counter = e->d_pos + 4; e->n_finished = e->d_pos + 8;
     HIP_TRY(hipMemset(e->d_pos, 0, 64));
     if ((r = A((void**)&e->n_tokens, (size_t)B * 4))) return r;
+    if ((r = A((void**)&e->row_n_prompt, (size_t)B * 4))) return r;
+    if ((r = A((void**)&e->row_sot, (size_t)B * 4))) return r;
+    if ((r = A((void**)&e->dyn, 64))) return r;
     if ((r = A((void**)&e->sum_logprob, (size_t)B * 4))) return r;
     if ((r = A((void**)&e->no_speech, (size_t)B * 4))) return r;
     if ((r = A((void**)&e->partial, (size_t)B * e->Ht * 8 * (HEAD_DIM + 2) * 4))) return r;
@@ -762,37 +767,55 @@ static SamplerArgs make_sampler(wx_engine* e, int B, const wx_decode_opts& o, in
     s.tok_no_timestamps = c.tok_no_timestamps; s.tok_timestamp_begin = c.tok_timestamp_begin;
     s.without_timestamps = o.without_timestamps; s.suppress_blank = o.suppress_blank; s.max_initial_ts = o.max_initial_timestamp_index;
     s.forced = forced;
+    if (!forced) { s.row_n_prompt = e->row_n_prompt; s.row_sot = e->row_sot; s.dyn = e->dyn; }
     return s;
 }
 
-int wx_decode_greedy(wx_engine* e, int32_t B, const int32_t* h_prompt, const wx_decode_opts* opts, int32_t* d_tokens,
-                     int32_t* d_n_tokens, float* d_sum_logprob, float* d_no_speech_prob, int32_t* h_steps, void* stream) {
+// Sampling decode of B rows with per-row prompts: h_rows [B][n_text_ctx] (prompt ids, rest ignored), h_np / h_sot [B].
+// temperature 0 = greedy.  Shared by wx_decode_greedy (one prompt for every row) and wx_decode_rows.
+static int decode_rows_impl(wx_engine* e, int32_t B, const int32_t* h_rows, const int32_t* h_np, const int32_t* h_sot,
+                            const wx_decode_opts* opts, float temperature, uint32_t seed, int32_t* d_tokens, int32_t* d_n_tokens,
+                            float* d_sum_logprob, float* d_no_speech_prob, int32_t* h_steps, void* stream) {
     if (!e || !e->finalized) return fail(WX_ERR_STATE, "engine not finalized");
-    if (!h_prompt || !opts || !d_tokens || !d_n_tokens || !d_sum_logprob || !d_no_speech_prob) return fail(WX_ERR_INVALID, "null argument");
+    if (!h_rows || !h_np || !h_sot || !opts || !d_tokens || !d_n_tokens || !d_sum_logprob || !d_no_speech_prob) return fail(WX_ERR_INVALID, "null argument");
     if (B <= 0 || B > e->encoded_B) return fail(WX_ERR_INVALID, "decode batch exceeds the last wx_encode batch");
+    if (!(temperature >= 0.f)) return fail(WX_ERR_INVALID, "temperature must be >= 0");
     const wx_config& c = e->cfg;
     e->beam_n = 0;
     wx_decode_opts o = *opts;
-    if (o.n_prompt <= 0 || o.n_prompt >= c.n_text_ctx || o.sot_index < 0 || o.sot_index >= o.n_prompt)
-        return fail(WX_ERR_INVALID, "bad prompt length / sot index");
-    for (int i = 0; i < o.n_prompt; ++i) if (h_prompt[i] < 0 || h_prompt[i] >= c.n_vocab) return fail(WX_ERR_INVALID, "prompt id out of range");
-    int sample_len = o.max_new_tokens > 0 ? o.max_new_tokens : c.n_text_ctx / 2;
-    if (o.n_prompt + sample_len > c.n_text_ctx) sample_len = c.n_text_ctx - o.n_prompt;   // upstream stops once len > n_ctx
+    int max_np = 0;
+    for (int b = 0; b < B; ++b) {
+        if (h_np[b] <= 0 || h_np[b] >= c.n_text_ctx || h_sot[b] < 0 || h_sot[b] >= h_np[b]) return fail(WX_ERR_INVALID, "bad prompt length / sot index");
+        for (int i = 0; i < h_np[b]; ++i) {
+            const int32_t id = h_rows[(size_t)b * c.n_text_ctx + i];
+            if (id < 0 || id >= c.n_vocab) return fail(WX_ERR_INVALID, "prompt id out of range");
+        }
+        if (h_np[b] > max_np) max_np = h_np[b];
+    }
+    o.n_prompt = max_np; o.sot_index = h_sot[0];
+    int sample_len = o.max_new_tokens > 0 ? o.max_new_tokens : c.n_text_ctx / 2;     // per-row cap; rows also stop at n_text_ctx
     if (o.check_interval < 1) o.check_interval = 8;
     StreamScope sc(e, stream);
     hipStream_t st = sc.st;
     // initial state
     {
         std::vector<int32_t> rows((size_t)B * c.n_text_ctx, c.tok_eot);
-        for (int b = 0; b < B; ++b) memcpy(&rows[(size_t)b * c.n_text_ctx], h_prompt, (size_t)o.n_prompt * 4);
+        for (int b = 0; b < B; ++b) memcpy(&rows[(size_t)b * c.n_text_ctx], h_rows + (size_t)b * c.n_text_ctx, (size_t)h_np[b] * 4);
+        const uint32_t dyn[3] = {0, seed, (uint32_t)sample_len};
+        uint32_t dynw[3] = {dyn[0], dyn[1], dyn[2]};
+        memcpy(&dynw[0], &temperature, 4);
         HIP_TRY(hipMemcpyAsync(e->tokens, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(e->row_n_prompt, h_np, (size_t)B * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(e->row_sot, h_sot, (size_t)B * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(e->dyn, dynw, 12, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemsetAsync(e->d_pos, 0, 64, st));
         HIP_TRY(hipMemsetAsync(e->sum_logprob, 0, (size_t)B * 4, st));
         HIP_TRY(hipMemsetAsync(e->no_speech, 0, (size_t)B * 4, st));
-        HIP_TRY(hipStreamSynchronize(st));   // rows is a stack-lifetime host buffer
+        HIP_TRY(hipStreamSynchronize(st));   // rows / dynw are stack-lifetime host buffers
     }
     const SamplerArgs sa = make_sampler(e, B, o, 0);
-    const int total_steps = o.n_prompt - 1 + sample_len;   // positions 0 .. n_prompt-2 feed the prompt, then sample_len sampling steps
+    int total_steps = max_np - 1 + sample_len;     // the longest prompt is fed, then up to sample_len sampling steps
+    if (total_steps > c.n_text_ctx - 1) total_steps = c.n_text_ctx - 1;
     hipGraphExec_t exec = nullptr;
     auto capture = [&](hipStream_t cs, auto&& body, hipGraphExec_t* out) -> int {
         hipGraph_t graph = nullptr;
@@ -807,7 +830,7 @@ int wx_decode_greedy(wx_engine* e, int32_t B, const int32_t* h_prompt, const wx_
         return 0;
     };
     if (o.use_graph) {
-        std::vector<int> key = {0, B, o.n_prompt, o.sot_index, o.without_timestamps, o.suppress_blank, o.max_initial_timestamp_index};
+        std::vector<int> key = {0, B, o.without_timestamps, o.suppress_blank, o.max_initial_timestamp_index};
         if (!e->graph_exec || e->graph_key != key) {
             if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
             e->graph_key.clear();
@@ -817,7 +840,8 @@ int wx_decode_greedy(wx_engine* e, int32_t B, const int32_t* h_prompt, const wx_
         }
         exec = e->graph_exec;
     }
-    int sampled = 0;
+    int sampled = 0, min_np = max_np;
+    for (int b = 0; b < B; ++b) if (h_np[b] < min_np) min_np = h_np[b];
     const bool want_prof = !exec && o.profile_stride > 0;
     if (want_prof && e->prof_events.empty()) {
         e->prof_events.resize((size_t)2 * c.n_text_layer * 32);
@@ -825,10 +849,10 @@ int wx_decode_greedy(wx_engine* e, int32_t B, const int32_t* h_prompt, const wx_
     }
     e->prof_used = 0; e->prof_ms = 0.0; e->prof_launches = 0;
     for (int s = 0; s < total_steps; ++s) {
-        e->prof_on = want_prof && s >= o.n_prompt - 1 && ((s - (o.n_prompt - 1)) % o.profile_stride == 0);
+        e->prof_on = want_prof && s >= min_np - 1 && ((s - (min_np - 1)) % o.profile_stride == 0);
         if (exec) HIP_TRY(hipGraphLaunch(exec, st));
         else { int r = decode_step(e, B, &sa, st); e->prof_on = false; if (r) return r; }
-        if (s >= o.n_prompt - 1) {
+        if (s >= min_np - 1) {
             ++sampled;
             if (sampled % o.check_interval == 0 && s + 1 < total_steps) {
                 HIP_TRY(hipMemcpyAsync(e->h_pinned, e->n_finished, 4, hipMemcpyDeviceToHost, st));
@@ -837,7 +861,7 @@ int wx_decode_greedy(wx_engine* e, int32_t B, const int32_t* h_prompt, const wx_
             }
         }
     }
-    WX_TRY(launch_finish_tokens(e->tokens, c.n_text_ctx, o.n_prompt, c.tok_eot, e->d_pos, e->n_tokens, B, st));
+    WX_TRY(launch_finish_tokens(e->tokens, c.n_text_ctx, 0, e->row_n_prompt, c.tok_eot, e->d_pos, e->n_tokens, B, st));
     HIP_TRY(hipMemcpyAsync(d_tokens, e->tokens, (size_t)B * c.n_text_ctx * 4, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_n_tokens, e->n_tokens, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_sum_logprob, e->sum_logprob, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
@@ -852,6 +876,27 @@ int wx_decode_greedy(wx_engine* e, int32_t B, const int32_t* h_prompt, const wx_
         }
     }
     return WX_OK;
+}
+
+int wx_decode_greedy(wx_engine* e, int32_t B, const int32_t* h_prompt, const wx_decode_opts* opts, int32_t* d_tokens,
+                     int32_t* d_n_tokens, float* d_sum_logprob, float* d_no_speech_prob, int32_t* h_steps, void* stream) {
+    if (!e || !e->finalized) return fail(WX_ERR_STATE, "engine not finalized");
+    if (!h_prompt || !opts) return fail(WX_ERR_INVALID, "null argument");
+    const int ctx = e->cfg.n_text_ctx;
+    if (B <= 0 || B > e->cfg.max_batch) return fail(WX_ERR_INVALID, "decode batch exceeds the last wx_encode batch");
+    if (opts->n_prompt <= 0 || opts->n_prompt >= ctx || opts->sot_index < 0 || opts->sot_index >= opts->n_prompt)
+        return fail(WX_ERR_INVALID, "bad prompt length / sot index");
+    std::vector<int32_t> rows((size_t)B * ctx, e->cfg.tok_eot), np(B, opts->n_prompt), sot(B, opts->sot_index);
+    for (int b = 0; b < B; ++b) memcpy(&rows[(size_t)b * ctx], h_prompt, (size_t)opts->n_prompt * 4);
+    return decode_rows_impl(e, B, rows.data(), np.data(), sot.data(), opts, 0.f, 0, d_tokens, d_n_tokens, d_sum_logprob, d_no_speech_prob,
+                            h_steps, stream);
+}
+
+int wx_decode_rows(wx_engine* e, int32_t B, const int32_t* h_prompts, const int32_t* h_n_prompt, const int32_t* h_sot_index,
+                   const wx_decode_opts* opts, float temperature, uint32_t seed, int32_t* d_tokens, int32_t* d_n_tokens,
+                   float* d_sum_logprob, float* d_no_speech_prob, int32_t* h_steps, void* stream) {
+    return decode_rows_impl(e, B, h_prompts, h_n_prompt, h_sot_index, opts, temperature, seed, d_tokens, d_n_tokens, d_sum_logprob,
+                            d_no_speech_prob, h_steps, stream);
 }
 
 int wx_decode_beam(wx_engine* e, int32_t B, int32_t beam_size, float patience, const int32_t* h_prompt, const wx_decode_opts* opts,

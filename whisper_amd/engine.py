@@ -178,6 +178,36 @@ class WhisperEngine:
         return {"tokens": tokens, "n_tokens": n_tokens, "sum_logprobs": sum_lp, "no_speech_probs": nsp,
                 "steps": int(steps.value), "n_prompt": len(prompt)}
 
+    def decode_rows(self, prompts: Sequence[Sequence[int]], temperature: float = 0.0, seed: int = 0, max_new_tokens: int = 0,
+                    without_timestamps: bool = True, suppress_blank: bool = True, max_initial_timestamp_index: int = 50,
+                    use_graph: bool = True, check_interval: int = 8) -> Dict[str, object]:
+        """Sampling decode with one prompt per window of the last encode (``len(prompts)`` rows); ``temperature`` 0 is
+        greedy.  Returns per-row token lists (after each row's own prompt, EOT excluded), sum_logprobs, no_speech_probs."""
+        B, ctx = len(prompts), self.dims.n_text_ctx
+        rows = np.full((B, ctx), self.tok.eot, np.int32)
+        n_prompt = np.zeros(B, np.int32); sot = np.zeros(B, np.int32)
+        for b, p in enumerate(prompts):
+            p = [int(x) for x in p]
+            rows[b, :len(p)] = p
+            n_prompt[b] = len(p); sot[b] = p.index(self.tok.sot)
+        opts = _lib.WxDecodeOpts(
+            n_prompt=0, sot_index=0, max_new_tokens=int(max_new_tokens), without_timestamps=int(without_timestamps),
+            suppress_blank=int(suppress_blank), max_initial_timestamp_index=int(max_initial_timestamp_index),
+            use_graph=int(use_graph), check_interval=int(check_interval), profile_stride=0)
+        dev = self.torch_device
+        tokens = torch.empty((B, ctx), dtype=torch.int32, device=dev)
+        n_tokens = torch.empty(B, dtype=torch.int32, device=dev)
+        sum_lp = torch.empty(B, dtype=torch.float32, device=dev)
+        nsp = torch.empty(B, dtype=torch.float32, device=dev)
+        steps = ctypes.c_int32(0)
+        _lib.check(self.lib.wx_decode_rows(self.handle, B, rows.ctypes.data_as(ctypes.c_void_p), n_prompt.ctypes.data_as(ctypes.c_void_p),
+                                           sot.ctypes.data_as(ctypes.c_void_p), ctypes.byref(opts), ctypes.c_float(temperature),
+                                           ctypes.c_uint32(seed & 0xFFFFFFFF), _ptr(tokens), _ptr(n_tokens), _ptr(sum_lp), _ptr(nsp),
+                                           ctypes.byref(steps), self._stream()), "wx_decode_rows")
+        t_cpu, n_cpu = tokens.cpu().numpy(), n_tokens.cpu().numpy()
+        out = [t_cpu[b, n_prompt[b]:n_prompt[b] + int(n_cpu[b])].tolist() for b in range(B)]
+        return {"tokens": out, "sum_logprobs": sum_lp.cpu().tolist(), "no_speech_probs": nsp.cpu().tolist(), "steps": int(steps.value)}
+
     def decode_beam(self, B: int, prompt: Sequence[int], beam_size: int = 5, patience: float = 1.0, max_new_tokens: int = 0,
                     without_timestamps: bool = True, suppress_blank: bool = True, max_initial_timestamp_index: int = 50,
                     use_graph: bool = True, check_interval: int = 8) -> Dict[str, object]:
