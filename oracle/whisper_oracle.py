@@ -494,3 +494,106 @@ def transcribe_windows(model: OracleWhisper, audio: np.ndarray, init_tokens: Seq
         toks += r["tokens"]; sums += list(r["sum_logprobs"]); nsp += list(r["no_speech_probs"])
     return {"tokens": toks, "sum_logprobs": np.array(sums, np.float32), "no_speech_probs": np.array(nsp, np.float32),
             "n_windows": n_win, "mel": mel}
+
+
+# -------------------------------------------------------------------------------------------------
+# sequential long-form loop
+# -------------------------------------------------------------------------------------------------
+
+def compression_ratio(text: str) -> float:
+    import zlib
+    b = text.encode("utf-8")
+    return len(b) / len(zlib.compress(b))
+
+
+def transcribe_sequential(model: OracleWhisper, audio: np.ndarray, tok, suppress_ids: Sequence[int], decode_text,
+                          language_index: int = 0, initial_prompt_ids: Optional[Sequence[int]] = None,
+                          compression_ratio_threshold: Optional[float] = 2.4, logprob_threshold: Optional[float] = -1.0,
+                          no_speech_threshold: Optional[float] = 0.6, condition_on_previous_text: bool = True,
+                          max_new_tokens: Optional[int] = None) -> Dict[str, object]:
+    """Upstream ``Whisper.transcribe`` main loop at temperature 0 [upstream-recall; the same loop in the HF port is
+    hf:models/whisper/generation_whisper.py:785-903 (loop), :1853-1918 (prompt), :1977-2074 (segments / seek), :1243-1287
+    (fallback checks)]: whole-file log-mel with 30 s of padding; ``while seek < content_frames``: cut 3000 frames at
+    ``seek``, decode with timestamps and the previous text as prompt (``[sot_prev] + all_tokens[-223:] + sot sequence``),
+    skip the window if it looks like silence (no_speech_prob > threshold and avg_logprob <= logprob threshold), split the
+    ids at consecutive timestamp pairs into segments, advance ``seek`` by the last timestamp (x2 frames) or by the whole
+    window.  Only temperature 0 is restated: the fallback decision is computed and reported (``needs_fallback``) but the
+    sampled re-decodes at T > 0 depend on torch's global generator and are not part of the parity surface."""
+    dims = model.dims
+    mel = log_mel_spectrogram(audio, dims.n_mels, padding=N_SAMPLES)
+    content_frames = mel.shape[-1] - N_FRAMES
+    seek = 0
+    all_tokens: List[int] = list(initial_prompt_ids or [])
+    prompt_reset_since = 0
+    segments: List[Dict[str, object]] = []
+    windows = 0
+    tb = tok.timestamp_begin
+    while seek < content_frames:
+        time_offset = seek * HOP_LENGTH / SAMPLE_RATE
+        segment_size = min(N_FRAMES, content_frames - seek)
+        segment_duration = segment_size * HOP_LENGTH / SAMPLE_RATE
+        mel_segment = pad_or_trim_frames(mel[:, seek:seek + segment_size])
+        prompt = all_tokens[prompt_reset_since:]
+        init = initial_tokens(tok, language_index, without_timestamps=False, prompt_ids=prompt, n_text_ctx=dims.n_text_ctx)
+        with torch.no_grad():
+            r = greedy_decode(model, model.encode(mel_segment[None]), init, tok, suppress_ids, max_new_tokens=max_new_tokens,
+                              without_timestamps=False)
+        windows += 1
+        tokens = r["tokens"][0]
+        avg_logprob = float(r["avg_logprobs"][0]); no_speech_prob = float(r["no_speech_probs"][0])
+        text = decode_text(tokens).strip()
+        cr = compression_ratio(text) if text else 0.0
+        needs_fallback = False
+        if compression_ratio_threshold is not None and cr > compression_ratio_threshold:
+            needs_fallback = True
+        if logprob_threshold is not None and avg_logprob < logprob_threshold:
+            needs_fallback = True
+        if no_speech_threshold is not None and no_speech_prob > no_speech_threshold:
+            needs_fallback = False
+        if no_speech_threshold is not None:
+            should_skip = no_speech_prob > no_speech_threshold
+            if logprob_threshold is not None and avg_logprob > logprob_threshold:
+                should_skip = False
+            if should_skip:
+                seek += segment_size
+                continue
+        current: List[Dict[str, object]] = []
+
+        def new_segment(start, end, toks):
+            return {"seek": seek, "start": start, "end": end, "tokens": list(toks), "text": decode_text([t for t in toks if t < tok.eot]),
+                    "temperature": 0.0, "avg_logprob": avg_logprob, "compression_ratio": cr, "no_speech_prob": no_speech_prob,
+                    "needs_fallback": needs_fallback}
+        is_ts = [t >= tb for t in tokens]
+        single_timestamp_ending = is_ts[-2:] == [False, True]
+        consecutive = [i + 1 for i in range(len(tokens) - 1) if is_ts[i] and is_ts[i + 1]]
+        if consecutive:
+            slices = list(consecutive)
+            if single_timestamp_ending:
+                slices.append(len(tokens))
+            last_slice = 0
+            for cur in slices:
+                sl = tokens[last_slice:cur]
+                current.append(new_segment(time_offset + (sl[0] - tb) * 0.02, time_offset + (sl[-1] - tb) * 0.02, sl))
+                last_slice = cur
+            if single_timestamp_ending:
+                seek_next = seek + segment_size
+            else:
+                seek_next = seek + (tokens[last_slice - 1] - tb) * 2
+        else:
+            duration = segment_duration
+            ts = [t for t in tokens if t >= tb]
+            if ts and ts[-1] != tb:
+                duration = (ts[-1] - tb) * 0.02
+            current.append(new_segment(time_offset, time_offset + duration, tokens))
+            seek_next = seek + segment_size
+        for sg in current:
+            if sg["start"] == sg["end"] or sg["text"].strip() == "":
+                sg["text"] = ""; sg["tokens"] = []
+        segments.extend(current)
+        for sg in current:
+            all_tokens.extend(sg["tokens"])
+        if not condition_on_previous_text:
+            prompt_reset_since = len(all_tokens)
+        seek = seek_next
+    return {"segments": segments, "windows": windows, "tokens": all_tokens[len(initial_prompt_ids or []):],
+            "text": decode_text([t for t in all_tokens[len(initial_prompt_ids or []):] if t < tok.eot])}

@@ -245,3 +245,54 @@ def test_beam_search_bf16_shares_cross_kv(models):
     assert len(b5["tokens"]) == 3 and all(len(c) >= 5 for c in b5["candidates"])
     for b in range(3):     # the best beam can only score at least as well as the greedy path under the same model
         assert max(c[1] / max(len(c[0]), 1) for c in b5["candidates"][b]) >= g["sum_logprobs"].cpu()[b].item() / max(len(greedy[b]), 1) - 1e-2
+
+
+def test_sequential_long_form_matches_oracle_fp32(models):
+    """Upstream's sequential loop (timestamps, previous-text prompt, timestamp-driven seek) at temperature 0: two files of
+    different length decoded in lockstep (one batch per iteration, per-row prompts) give, file by file, the oracle's
+    segments -- seek, start, end, ids -- and the same number of decoded windows."""
+    from whisper_amd.longform import transcribe_sequential
+    from whisper_amd.tokenizer import Tokenizer
+    dims, sd, eng = models("micro", "fp32", eot_boost=3.0)
+    om = wo.OracleWhisper(dims, sd)
+    tok = eng.tok
+    dec = Tokenizer(dims.n_vocab).decode
+    sup = wo.suppress_token_ids(tok, ck.non_speech_suppress_ids())
+    audios = [wo.varied_audio(31, 16000 * 70), wo.varied_audio(32, 16000 * 35 + 777)]
+    got = transcribe_sequential(eng, audios, dec, language_index=0, temperatures=(0.0,), max_new_tokens=20)
+    for a, g in zip(audios, got):
+        ref = wo.transcribe_sequential(om, a, tok, sup, dec, language_index=0, max_new_tokens=20)
+        assert g["windows"] == ref["windows"] and g["tokens"] == ref["tokens"]
+        assert [(s["seek"], s["tokens"]) for s in g["segments"]] == [(s["seek"], s["tokens"]) for s in ref["segments"]]
+        np.testing.assert_allclose([s["start"] for s in g["segments"]], [s["start"] for s in ref["segments"]], atol=1e-9)
+        np.testing.assert_allclose([s["end"] for s in g["segments"]], [s["end"] for s in ref["segments"]], atol=1e-9)
+        np.testing.assert_allclose([s["avg_logprob"] for s in g["segments"]], [s["avg_logprob"] for s in ref["segments"]], rtol=1e-4, atol=1e-3)
+        assert [s["needs_fallback"] for s in g["segments"]] == [s["needs_fallback"] for s in ref["segments"]]
+    # every window looks like silence under an absurd threshold: all skipped, nothing emitted, same window count
+    skipped = transcribe_sequential(eng, audios[1:], dec, temperatures=(0.0,), no_speech_threshold=1e-12, max_new_tokens=8)[0]
+    ref = wo.transcribe_sequential(om, audios[1], tok, sup, dec, no_speech_threshold=1e-12, max_new_tokens=8)
+    assert skipped["segments"] == [] and ref["segments"] == [] and skipped["windows"] == ref["windows"] == 2
+
+
+def test_temperature_fallback_sampling(models):
+    """T > 0 re-decodes (upstream decode_with_fallback): reproducible for a given seed, different across seeds, ids obey the
+    logit filters, and a vanishing temperature reproduces greedy decoding."""
+    dims, sd, eng = models("micro", "fp32", eot_boost=3.0)
+    mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(s), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000] for s in range(2)])
+    eng.encode_windows(mels)
+    tok = eng.tok
+    prompts = [eng.initial_tokens(0, without_timestamps=False), eng.initial_tokens(0, without_timestamps=False, prompt_ids=[100, 200, 300])]
+    g = eng.decode_rows(prompts, temperature=0.0, max_new_tokens=16, without_timestamps=False)
+    cold = eng.decode_rows(prompts, temperature=1e-4, seed=5, max_new_tokens=16, without_timestamps=False)
+    assert cold["tokens"] == g["tokens"]
+    a = eng.decode_rows(prompts, temperature=1.0, seed=7, max_new_tokens=16, without_timestamps=False)
+    b = eng.decode_rows(prompts, temperature=1.0, seed=7, max_new_tokens=16, without_timestamps=False)
+    c = eng.decode_rows(prompts, temperature=1.0, seed=8, max_new_tokens=16, without_timestamps=False)
+    assert a["tokens"] == b["tokens"] and a["tokens"] != c["tokens"] and a["tokens"] != g["tokens"]
+    sup = set(eng.suppress_ids)
+    for row in a["tokens"] + c["tokens"]:
+        assert all(0 <= t < dims.n_vocab and t not in sup and t != tok.no_timestamps for t in row)
+        assert row[0] >= tok.timestamp_begin                      # timestamp rules: a window starts with a timestamp
+        ts = [t for t in row if t >= tok.timestamp_begin]
+        assert ts == sorted(ts)                                   # ... and timestamps never decrease
+    assert all(lp < 0 for lp in a["sum_logprobs"])

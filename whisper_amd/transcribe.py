@@ -114,8 +114,13 @@ def _prompt_ids(prompt, tokenizer: Tokenizer) -> Optional[List[int]]:
 
 
 def transcribe(audio, language: Optional[str] = None, prompt: Union[None, str, Sequence[int]] = None,
-               **decode_kw) -> Dict[str, object]:
-    """``decode_kw``: ``beam_size`` (None = greedy, upstream's default for the reference's call), ``patience``,
+               mode: str = "windows", **decode_kw) -> Dict[str, object]:
+    """``mode="windows"`` (default): independent 30 s windows, batched and sharded across ranks.
+    ``mode="sequential"``: upstream's faithful long-form loop (timestamps, previous-text prompt, timestamp-driven seek,
+    no-speech skip, temperature fallback; whisper_amd/longform.py) -- per file sequential, so every rank decodes the file
+    itself; the result additionally carries ``segments``.
+
+    ``decode_kw``: ``beam_size`` (None = greedy, upstream's default for the reference's call), ``patience``,
     ``max_new_tokens``, ``without_timestamps``.
 
     Returns ``{"text", "confidence", "chunks_processed"}`` plus ``language``, ``tokens`` (per window),
@@ -141,6 +146,18 @@ def transcribe(audio, language: Optional[str] = None, prompt: Union[None, str, S
         lang_idx = detect_language(eng, mel0, min(n_file, N_SAMPLES) // 160)
     else:
         lang_idx = language_index(language, eng.dims.n_vocab)
+    if mode == "sequential":
+        from .longform import transcribe_sequential
+        r = transcribe_sequential(eng, [pcm_host], tokenizer.decode, language_index=lang_idx,
+                                  initial_prompts=[_prompt_ids(prompt, tokenizer)], **decode_kw)[0]
+        lps = [sg["avg_logprob"] for sg in r["segments"]]
+        cmode = (_STATE["settings"] or {}).get("confidence_mode", "reference")
+        conf = 0.0 if cmode == "reference" or not lps else float(math.exp(sum(lps) / len(lps)))
+        return {"text": r["text"].strip(), "confidence": conf, "chunks_processed": int(r["windows"]),
+                "language": LANGUAGE_CODES[lang_idx], "tokens": r["tokens"], "segments": r["segments"],
+                "avg_logprob": lps, "no_speech_prob": [sg["no_speech_prob"] for sg in r["segments"]]}
+    if mode != "windows":
+        raise ValueError("mode must be 'windows' or 'sequential'")
     init = eng.initial_tokens(lang_idx, prompt_ids=_prompt_ids(prompt, tokenizer))
     res = wdist.transcribe_sharded(eng, pcm_host, init, **decode_kw)
     texts = [tokenizer.decode(t) for t in res["tokens"]]
