@@ -296,3 +296,41 @@ def test_temperature_fallback_sampling(models):
         ts = [t for t in row if t >= tok.timestamp_begin]
         assert ts == sorted(ts)                                   # ... and timestamps never decrease
     assert all(lp < 0 for lp in a["sum_logprobs"])
+
+
+def test_large_v3_full_size_bf16():
+    """BASELINE configs[2] dimensions (large-v3: d 1280, 20 heads, 32 + 32 layers, 128 mel bins, vocab 51866), bf16: encoder
+    output and teacher-forced logits of one window against the fp32 oracle, and the size-independent properties of the
+    decode path at full size: a window decodes to the same ids alone and inside a batch, with and without hipGraph replay,
+    rows are EOT padded, and the 256x256 encoder GEMM tiles / split-K decode GEMMs are the kernels that ran."""
+    from whisper_amd.engine import WhisperEngine
+    dims = ck.dims_for("large-v3")
+    sd = ck.synthetic_state_dict(dims, seed=0, attn_gain=1.0, eot_boost=3.0)
+    eng = WhisperEngine(dims, sd, precision="bf16", max_batch=4)
+    try:
+        mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(s), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000] for s in range(4)])
+        om = wo.OracleWhisper(dims, sd)
+        with torch.no_grad():
+            xa = om.encode(mels[:1])
+        eng.encode_windows(mels)
+        got = eng.encoder_output(4).cpu()
+        assert rms_err(got[:1], xa) < BF16_RMS_TOL
+        tok = eng.tok
+        toks = torch.tensor([[tok.sot, tok.lang(0), tok.transcribe, tok.no_timestamps, 100, 2000]])
+        with torch.no_grad():
+            ref = om.logits(toks, xa)
+        lg = eng.decoder_logits(toks.repeat(4, 1)).cpu()
+        assert rms_err(lg[:1], ref) < BF16_RMS_TOL
+        init = eng.initial_tokens(0)
+        a = eng.decode_greedy(4, init, max_new_tokens=12, use_graph=True)
+        b = eng.decode_greedy(4, init, max_new_tokens=12, use_graph=False)
+        ta = a["tokens"].cpu()
+        assert torch.equal(ta, b["tokens"].cpu())
+        eng.encode_windows(mels[2:3])
+        c = eng.decode_greedy(1, init, max_new_tokens=12)
+        assert torch.equal(c["tokens"].cpu()[0], ta[2])
+        na = a["n_tokens"].cpu()
+        for r in range(4):
+            assert (ta[r, len(init) + int(na[r]):] == tok.eot).all()
+    finally:
+        eng.close()
