@@ -683,8 +683,11 @@ static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, floa
     const size_t self_layer = (size_t)c.max_batch * e->n_pages_seq * e->Ht * KV_PAGE * HEAD_DIM;
     int n_split = 1;
     while (n_split < 6 && (B / (e->beam_n > 0 ? e->beam_n : 1)) * e->Ht * n_split < 512) ++n_split;
-    const int s_dd = decode_gemm_split(d, d), s_fc2 = decode_gemm_split(d, 4 * d), s_qkv = decode_gemm_split(3 * d, d),
-              s_fc1 = decode_gemm_split(4 * d, d);
+    // tuning hooks (WX_SPLIT_DD / FC2 / QKV / FC1 override the K-split of the four decode GEMM shapes)
+    static const int o_dd = getenv("WX_SPLIT_DD") ? atoi(getenv("WX_SPLIT_DD")) : 0, o_fc2 = getenv("WX_SPLIT_FC2") ? atoi(getenv("WX_SPLIT_FC2")) : 0,
+                     o_qkv = getenv("WX_SPLIT_QKV") ? atoi(getenv("WX_SPLIT_QKV")) : 0, o_fc1 = getenv("WX_SPLIT_FC1") ? atoi(getenv("WX_SPLIT_FC1")) : 0;
+    const int s_dd = o_dd ? o_dd : decode_gemm_split(d, d), s_fc2 = o_fc2 ? o_fc2 : decode_gemm_split(d, 4 * d),
+              s_qkv = o_qkv ? o_qkv : decode_gemm_split(3 * d, d), s_fc1 = o_fc1 ? o_fc1 : decode_gemm_split(4 * d, d);
     int pend_split = 0; const float* pend_bias = nullptr;       // residual update not yet folded into dx
     auto split_gemm = [&](const void* A, int64_t lda, const void* W, int K, int S) {
         GemmArgs g = gemm_basic(e, A, lda, W, B, d, K);
