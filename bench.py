@@ -122,9 +122,17 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     state = {}
 
-    def step(use_graph=True, profile_stride=0):
+    def step(use_graph=True, profile_stride=0, marks=None):
+        def mark():
+            if marks is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks.append(ev)
+        mark()
         mel = sharded_mel(eng, pcm, s_lo, n_file, w_lo, w_hi)
+        mark()
         eng.encode(mel, N_FRAMES, mel.stride(0), n_file // 160 - w_lo * N_FRAMES, B)
+        mark()
         if args.beam:
             rb = eng.decode_beam(B, prompt, beam_size=args.beam, max_new_tokens=args.max_new_tokens, use_graph=use_graph)
             toks = torch.full((B, dims.n_text_ctx), eng.tok.eot, dtype=torch.int32)
@@ -138,6 +146,7 @@ def main():
         if world > 1:      # result gather: padded ids + lengths, ~115 KB per rank
             out = wdist.all_gather(r["tokens"])
             lens = wdist.all_gather(r["n_tokens"])
+        mark()
         state["r"], state["mel"] = r, mel
         return r
 
@@ -160,6 +169,11 @@ def main():
         n_tokens = r["n_tokens"].float().mean().item()
 
         # dominant kernel: event-bracketed eager pass on the same batch
+        # per-stage device time of one more (untimed) step: events on the launch stream
+        marks = []
+        step(not args.no_graph, marks=marks)
+        torch.cuda.synchronize(dev)
+        st_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(3)]
         prof_ms, prof_n = 0.0, 0
         if not args.no_profile_pass and not args.beam:
             step(use_graph=False, profile_stride=8)
@@ -204,6 +218,20 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms, "launches_timed": prof_n,
             },
+        }
+        # stage rooflines (SURVEY §8d formulas; encoder FLOPs include the cross-K/V projection)
+        d_, L_, Ld_, nm_ = dims.n_audio_state, dims.n_audio_layer, dims.n_text_layer, dims.n_mels
+        mel_bytes = B * (N_SAMPLES * 4 + 2 * nm_ * N_FRAMES * 4 + nm_ * N_FRAMES * 4)      # stage 1 read+write, stage 2 read+write
+        enc_flop = B * (6 * nm_ * d_ * 3000 + 6 * d_ * d_ * 1500 + L_ * (24 * d_ * d_ * 1500 + 4 * 1500 * 1500 * d_) + 4 * d_ * d_ * 1500 * Ld_)
+        rows = B * max(1, args.beam)
+        t_avg = len(prompt) + steps_per_window / 2
+        dec_bytes = (steps_per_window + len(prompt) - 1) * (B * Ld_ * 2 * 1500 * d_ * es + rows * Ld_ * 2 * t_avg * d_ * es
+                                                             + (16 * d_ * d_ * Ld_ + dims.n_vocab * d_) * es)
+        out["stages"] = {
+            "mel": {"ms": st_ms[0], "achieved_GBs": mel_bytes / st_ms[0] / 1e6, "peak_GBs": HBM_PEAK_GBS, "bound": "hbm"},
+            "encoder": {"ms": st_ms[1], "achieved_TFLOPs": enc_flop / st_ms[1] / 1e9, "peak_TFLOPs": 2500.0, "bound": "mfma"},
+            "decode": {"ms": st_ms[2], "achieved_GBs": dec_bytes / st_ms[2] / 1e6, "peak_GBs": HBM_PEAK_GBS, "bound": "hbm",
+                       "ms_per_token_step": st_ms[2] / max(1, steps_per_window + len(prompt) - 1)},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(dims, sd, tok, eng.suppress_ids, steps_per_window, args.cpu_decode_steps)

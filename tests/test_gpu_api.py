@@ -166,3 +166,28 @@ def test_pcm16_ingest_and_wav_path_bit_exact(tmp_path):
         assert a["tokens"] == b["tokens"] and a["chunks_processed"] == 2
     finally:
         tx.close()
+
+
+def test_transcribe_modes_beam_and_sequential(tmp_path):
+    """The north-star entry point with upstream's other decoding options: beam search and the sequential long-form loop
+    return the same contract keys; chunks_processed counts decoded windows; an empty input is an empty result."""
+    from oracle import whisper_oracle as wo
+    from whisper_amd import transcribe as tx
+    tx.configure(model="micro", precision="fp32", max_batch=10, allow_synthetic_weights=True)
+    try:
+        audio = wo.varied_audio(9, 16000 * 45)
+        g = tx.transcribe(audio, language="en", max_new_tokens=10)
+        b = tx.transcribe(audio, language="en", max_new_tokens=10, beam_size=5)
+        s = tx.transcribe(audio, language="en", mode="sequential", max_new_tokens=10, temperatures=(0.0,))
+        for r in (g, b, s):
+            assert set(("text", "confidence", "chunks_processed", "language", "tokens")) <= set(r)
+            assert r["confidence"] == 0.0 and r["language"] == "en"
+        assert g["chunks_processed"] == b["chunks_processed"] == 2 and len(b["tokens"]) == 2
+        assert s["chunks_processed"] >= 2 and all(sg["end"] >= sg["start"] for sg in s["segments"])
+        assert [sg["seek"] for sg in s["segments"]] == sorted(sg["seek"] for sg in s["segments"])
+        e = tx.transcribe(np.zeros(0, np.float32), language="en")
+        assert e["text"] == "" and e["chunks_processed"] == 0
+        with pytest.raises(ValueError):
+            tx.transcribe(audio, language="en", mode="nope")
+    finally:
+        tx.close()
