@@ -64,6 +64,9 @@ def load() -> ctypes.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP extension has not been built (run `python -m whisper_amd.build`). "
             "whisper_amd has no CPU fallback.")
+    # PyTorch-ROCm wheels bundle their own libamdhip64; this library links the system one.  Whichever HIP runtime is
+    # loaded first owns the device, and the other then reports "no ROCm-capable device" -- load torch's first, always.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)   # AttributeError here means header and library disagree
