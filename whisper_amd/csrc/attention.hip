@@ -99,17 +99,17 @@ __device__ __forceinline__ void load_head_rows(const AttnArgs& a, int b, int h, 
 // heads per workgroup, so a batch-64 launch is 320 workgroups that are all resident at once.  Round trip 1 fetches
 // everything that depends on no other load (position, page-table row, q/k/v partial tiles); round trip 2 is the K/V
 // stream: <= 448 keys, 64 keys (8 KiB K + 8 KiB V in bf16) per iteration in flight per wave.
-template <typename T, int NWH>
-__global__ __launch_bounds__(256 * NWH) void attn_self_decode_kernel(AttnArgs a) {
+template <typename T, int NWH, int HPB = 4>
+__global__ __launch_bounds__(64 * HPB * NWH) void attn_self_decode_kernel(AttnArgs a) {
     typedef Chunk<T> C;
     constexpr int EPL = C::EPL, LPK = HEAD_DIM / EPL, KPI = 64 / LPK, U = 8, IT = KPI * U;
-    __shared__ float s_row[4][3][HEAD_DIM];
-    __shared__ int s_pt[4][448];                 // page-table row (page size 16: 28 entries; page size 1: n_text_ctx)
-    __shared__ float s_m[4][NWH], s_l[4][NWH];
-    __shared__ float s_o[4][NWH][HEAD_DIM];
+    __shared__ float s_row[HPB][3][HEAD_DIM];
+    __shared__ int s_pt[HPB][448];                 // page-table row (page size 16: 28 entries; page size 1: n_text_ctx)
+    __shared__ float s_m[HPB][NWH], s_l[HPB][NWH];
+    __shared__ float s_o[HPB][NWH][HEAD_DIM];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int hs = wid / NWH, kw = wid % NWH;          // head slot in the workgroup, key-split wave of that head
-    int bh = blockIdx.x * 4 + hs;
+    int bh = blockIdx.x * HPB + hs;
     const bool valid = bh < a.B * a.H;
     if (!valid) bh = a.B * a.H - 1;
     const int b = bh / a.H, h = bh % a.H;
@@ -477,13 +477,11 @@ int launch_attn_decode(const AttnArgs& a, hipStream_t st) {
     const bool paged = a.page_table != nullptr;
     if (paged) {
         if (!a.d_pos || !a.Kpool || !a.Vpool || a.pt_ld > 448 || (a.page_size != 1 && a.page_size != KV_PAGE) || a.n_split != 1 || (!a.q_partial && (!a.Knew || !a.Vnew))) return -1;
-        static const int nwh = getenv("WX_SELF_NWH") ? atoi(getenv("WX_SELF_NWH")) : 2;
+        // 2 waves per head x 4 heads per workgroup measured best over {1,2,4} x {1,2,4,8} (tools/microbench): fewer, fatter
+        // workgroups lose at long histories, more workgroups pay ~5 ns of dispatch each at short ones
         dim3 grid((a.B * a.H + 3) / 4);
-        if (a.dt == DT_BF16) {
-            if (nwh == 1) hipLaunchKernelGGL((attn_self_decode_kernel<bf16, 1>), grid, dim3(256), 0, st, a);
-            else if (nwh == 4) hipLaunchKernelGGL((attn_self_decode_kernel<bf16, 4>), grid, dim3(1024), 0, st, a);
-            else hipLaunchKernelGGL((attn_self_decode_kernel<bf16, 2>), grid, dim3(512), 0, st, a);
-        } else hipLaunchKernelGGL((attn_self_decode_kernel<float, 2>), grid, dim3(512), 0, st, a);
+        if (a.dt == DT_BF16) hipLaunchKernelGGL((attn_self_decode_kernel<bf16, 2>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((attn_self_decode_kernel<float, 2>), grid, dim3(512), 0, st, a);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     if (!a.K || !a.V || a.n_keys <= 0) return -1;
