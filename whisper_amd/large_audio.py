@@ -76,36 +76,45 @@ async def transcribe_audio_local(audio_path: Path, detailed: bool = True, langua
         return "", 0.0, "unknown", "failed"
 
 
+def _carry_prompt(prompt: Optional[str], previous_text: Optional[str]) -> Optional[str]:
+    """Prompt of a piece: the caller's prompt, plus the last 20 words of the piece before it (ref :300-310)."""
+    if previous_text is None:
+        return prompt
+    tail = " ".join(previous_text.split()[-20:])
+    return f"{prompt or ''} Previous context: {tail}"
+
+
+def _remove_pieces(pieces: List[Path], original: Path) -> None:
+    """Delete the piece files and their (then empty) directory; never the caller's file (ref :323-337)."""
+    own = [p for p in pieces if p != original]
+    for p in own:
+        try:
+            p.unlink()
+        except OSError:
+            pass
+    if own and own[0].parent.exists():
+        try:
+            own[0].parent.rmdir()
+        except OSError:
+            pass
+
+
 async def transcribe_large_audio(audio_path: Path, detailed: bool = True, language: Optional[str] = None,
                                  prompt: Optional[str] = None) -> Tuple[str, float, str, str]:
     audio_path = Path(audio_path)
-    file_size_mb = audio_path.stat().st_size / (1024 * 1024)
-    if file_size_mb <= MAX_SINGLE_CALL_MB:
+    if audio_path.stat().st_size / (1024 * 1024) <= MAX_SINGLE_CALL_MB:
         return await transcribe_audio_local(audio_path, detailed, language, prompt)
-    chunks = await chunk_large_audio(audio_path)
+    pieces = await chunk_large_audio(audio_path)
+    results: List[Tuple[str, float, str]] = []
     try:
-        transcriptions, confidences, languages = [], [], []
-        for i, chunk_path in enumerate(chunks):
-            chunk_prompt = prompt
-            if i > 0 and transcriptions:
-                prev_text = transcriptions[-1].split()[-20:]      # last 20 words (:304)
-                chunk_prompt = f"{prompt or ''} Previous context: {' '.join(prev_text)}"
-            text, conf, lang, _source = await transcribe_audio_local(chunk_path, detailed, language, chunk_prompt)
-            transcriptions.append(text); confidences.append(conf); languages.append(lang)
-        combined_text = " ".join(transcriptions)
-        avg_confidence = sum(confidences) / len(confidences) if confidences else 0.0
-        primary_language = max(set(languages), key=languages.count) if languages else "unknown"
-        return combined_text, avg_confidence, primary_language, "chunked"
+        for piece in pieces:
+            carried = _carry_prompt(prompt, results[-1][0] if results else None)
+            text, conf, lang, _ = await transcribe_audio_local(piece, detailed, language, carried)
+            results.append((text, conf, lang))
     finally:
-        for chunk_path in chunks:
-            if chunk_path != audio_path:
-                try:
-                    chunk_path.unlink()
-                except Exception:   # noqa: BLE001
-                    pass
-        chunk_dir = chunks[0].parent if chunks and chunks[0] != audio_path else None
-        if chunk_dir and chunk_dir.exists():
-            try:
-                chunk_dir.rmdir()
-            except Exception:   # noqa: BLE001
-                pass
+        _remove_pieces(pieces, audio_path)
+    if not results:
+        return "", 0.0, "unknown", "chunked"
+    langs = [r[2] for r in results]
+    return (" ".join(r[0] for r in results), sum(r[1] for r in results) / len(results),
+            max(set(langs), key=langs.count), "chunked")
