@@ -178,6 +178,53 @@ def test_long_form_matches_oracle_fp32(models):
     assert r["tokens"] == ref["tokens"]
 
 
+@pytest.mark.parametrize("n_samples", [1, 150, 399, 401, wo.N_SAMPLES - 1, wo.N_SAMPLES, wo.N_SAMPLES + 1, wo.N_SAMPLES + 160])
+def test_edge_lengths_match_oracle_fp32(models, n_samples):
+    """Clips shorter than one FFT window (the reflect padding then reaches into the zero padding), of exactly one 30 s
+    window, one sample longer (still one window: upstream counts whole 160-sample frames) and one frame longer (a second
+    window that holds a single frame): mel, window count and token ids equal the oracle's."""
+    dims, sd, eng = models("micro", "fp32", max_batch=2, eot_boost=3.0)
+    om = wo.OracleWhisper(dims, sd)
+    tok = eng.tok
+    audio = wo.varied_audio(23, n_samples)
+    init = wo.initial_tokens(tok, 0)
+    with torch.no_grad():
+        ref = wo.transcribe_windows(om, audio, init, tok, wo.suppress_token_ids(tok, ck.non_speech_suppress_ids()), max_new_tokens=12)
+    got_mel = eng.log_mel(torch.from_numpy(audio)).cpu().numpy()
+    assert got_mel.shape == tuple(ref["mel"].shape)
+    assert rel_err(got_mel, ref["mel"].numpy()) < 1e-4
+    r = eng.transcribe_pcm(audio, init, max_new_tokens=12)
+    assert r["n_windows"] == ref["n_windows"] == max(1, -(-(n_samples // 160) // 3000))
+    assert r["tokens"] == ref["tokens"]
+
+
+def test_long_prompt_fills_the_text_context_fp32(models):
+    """A previous-text prompt longer than n_text_ctx/2 - 1 keeps its last 223 ids (upstream _get_initial_tokens), and
+    decoding then runs until the text context is full: the longest decode the engine can be asked for."""
+    dims, sd, eng = models("micro", "fp32", max_batch=2, eot_boost=0.0)
+    om = wo.OracleWhisper(dims, sd)
+    tok = eng.tok
+    rng = np.random.default_rng(5)
+    prompt = [int(x) for x in rng.integers(0, tok.eot, size=300)]
+    init = eng.initial_tokens(0, prompt_ids=prompt)
+    assert init == wo.initial_tokens(tok, 0, prompt_ids=prompt, n_text_ctx=dims.n_text_ctx)
+    assert len(init) == 1 + (dims.n_text_ctx // 2 - 1) + 4
+    mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(s), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000] for s in range(2)])
+    with torch.no_grad():
+        ref = wo.greedy_decode(om, om.encode(mels), init, tok, wo.suppress_token_ids(tok, ck.non_speech_suppress_ids()))
+    eng.encode_windows(mels)
+    r = eng.decode_greedy(2, init)
+    n = r["n_tokens"].cpu().tolist()
+    t = r["tokens"].cpu()
+    room = dims.n_text_ctx - len(init)
+    for b in range(2):
+        # Known one-id divergence at the context limit (DESIGN.md "Divergences"): upstream's loop stops once the row holds
+        # n_text_ctx + 1 ids (it still samples from position n_text_ctx - 1); the engine's rows hold n_text_ctx ids.
+        assert len(ref["tokens"][b]) <= room + 1
+        assert t[b, len(init):len(init) + n[b]].tolist() == ref["tokens"][b][:room]
+        assert n[b] == min(len(ref["tokens"][b]), room)
+
+
 def test_bf16_greedy_agrees_with_oracle_where_margin_is_large(models):
     dims, sd, eng = models("tiny", "bf16")
     om = wo.OracleWhisper(dims, sd)
