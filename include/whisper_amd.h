@@ -79,6 +79,18 @@ int wx_finalize(wx_engine* e);
  * d_pcm16 and d_out must be 16-byte aligned. */
 int wx_pcm16_to_f32(wx_engine* e, const int16_t* d_pcm16, int64_t n, float* d_out, void* stream);
 
+/* replaces the reference's ffmpeg normalisation step (ref:app/audio/processor.py:136-147: `acodec=pcm_s16le, ar=16000,
+ * ac=1`) for PCM16 input of any rate and channel count: channel average, then a polyphase windowed-sinc resampler
+ * y[n] = sum_m x[m] * h[half_len + n*down - m*up]  (up/down = 16000/src_rate reduced; x is 0 outside the file), i.e.
+ * scipy.signal.resample_poly's arithmetic with the caller's centred taps h_taps[2*half_len + 1] (host, already scaled by
+ * `up`).  d_pcm16: interleaved [n_frames][n_channels] int16 on the device.  d_out: n_out = ceil(n_frames*up/down) mono
+ * float32 samples in [-1, 1).  quantize != 0 rounds every output to the int16 grid (round-half-even, clipped), as the
+ * reference's intermediate s16le WAV does.  ffmpeg's own filter differs (and is absent here): parity with ffmpeg is
+ * unpinned; the oracle is a numpy restatement pinned against scipy.signal.resample_poly.
+ * Limits: 1 <= n_channels <= 8, down <= 8*up, 2*half_len + 1 <= 65536. */
+int wx_resample_pcm16(wx_engine* e, const int16_t* d_pcm16, int64_t n_frames, int32_t n_channels, int32_t up, int32_t down,
+                      const float* h_taps, int32_t half_len, int32_t quantize, float* d_out, int64_t n_out, void* stream);
+
 /* replaces whisper.log_mel_spectrogram inside Whisper.transcribe (ref:speech_recognition.py:55).
  * Stage 1: frames [frame0, frame0+n_frames) of the file -> d_logmel[m * ld + (f - frame0)] =
  *          log10(max(mel, 1e-10)), and atomically folds the slice maximum into *d_max (init with wx_mel_reset_max).

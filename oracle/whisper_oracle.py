@@ -35,6 +35,61 @@ N_FRAMES = N_SAMPLES // HOP_LENGTH          # 3000 mel frames per window
 
 
 # -------------------------------------------------------------------------------------------------
+# audio ingest: the reference's ffmpeg normalisation step (any PCM16 -> 16 kHz mono s16le)
+# -------------------------------------------------------------------------------------------------
+
+def resample_taps(up: int, down: int):
+    """Default low-pass of scipy.signal.resample_poly (scipy 1.15.3 signal/_signaltools.py, ``resample_poly``:
+    ``firwin(2*half_len + 1, 1/max_rate, window=('kaiser', 5.0))`` with ``half_len = 10*max_rate``, times ``up``),
+    rounded to float32 as the device table is."""
+    q = max(up, down)
+    half_len = 10 * q
+    n = np.arange(2 * half_len + 1, dtype=np.float64) - half_len
+    cutoff = 1.0 / q
+    win = np.i0(5.0 * np.sqrt(np.clip(1.0 - (n / half_len) ** 2, 0.0, 1.0))) / np.i0(5.0)      # Kaiser window, beta 5
+    h = cutoff * np.sinc(cutoff * n) * win
+    h = h / h.sum()                                                                               # firwin(scale=True): unit DC gain
+    return (h * up).astype(np.float32), half_len
+
+
+def resample_pcm16(pcm: np.ndarray, src_rate: int, quantize: bool = True) -> np.ndarray:
+    """int16 ``[n_frames]`` / ``[n_frames, n_channels]`` at ``src_rate`` -> mono float32 at 16 kHz.
+
+    What ``ffmpeg -acodec pcm_s16le -ar 16000 -ac 1`` does in the reference (ref:app/audio/processor.py:136-147) followed
+    by upstream load_audio's ``/ 32768``: mix the channels down by averaging, resample, round to the int16 grid.  ffmpeg is
+    absent here and its resampling filter is its own, so parity with ffmpeg is UNPINNED; the arithmetic restated here is
+    scipy.signal.resample_poly's (zero-stuffed up-sampling by ``up``, the centred FIR above, decimation by ``down``,
+    zeros beyond both ends, ``ceil(n*up/down)`` outputs), which tests/test_oracle_vs_golden.py pins against scipy itself."""
+    x = np.asarray(pcm)
+    if x.ndim == 1:
+        x = x[:, None]
+    g = math.gcd(SAMPLE_RATE, int(src_rate))
+    up, down = SAMPLE_RATE // g, int(src_rate) // g
+    mono = x.astype(np.float64).sum(axis=1) / (32768.0 * x.shape[1])
+    y = resample_poly_f64(mono, up, down)
+    if quantize:
+        y = np.clip(np.rint(y * 32768.0), -32768, 32767) / 32768.0
+    return y.astype(np.float32)
+
+
+def resample_poly_f64(x: np.ndarray, up: int, down: int) -> np.ndarray:
+    """y[n] = sum_m x[m] * h[half_len + n*down - m*up] over the m that fall under the filter, float64 accumulation."""
+    h32, half_len = resample_taps(up, down)
+    h = h32.astype(np.float64)
+    n_in = x.shape[0]
+    n_out = -(-n_in * up // down)
+    n = np.arange(n_out, dtype=np.int64)
+    first = -((half_len - n * down) // up)              # ceil((n*down - half_len) / up)
+    y = np.zeros(n_out, np.float64)
+    for j in range(2 * half_len // up + 1):
+        m = first + j
+        idx = half_len + n * down - m * up
+        ok = (m >= 0) & (m < n_in) & (idx >= 0)
+        y[ok] += x[m[ok]] * h[idx[ok]]
+    return y
+
+
+# -------------------------------------------------------------------------------------------------
 # log-mel front end
 # -------------------------------------------------------------------------------------------------
 

@@ -168,6 +168,48 @@ def test_pcm16_ingest_and_wav_path_bit_exact(tmp_path):
         tx.close()
 
 
+def test_resample_ingest_matches_oracle(tmp_path):
+    """wx_resample_pcm16 (channel average + polyphase resampling on the device, the reference's ffmpeg normalisation step)
+    against the oracle's float64 restatement: within fp32 accumulation error before quantisation, at most one int16 step
+    apart (and almost always equal) after it; a 44.1 kHz stereo WAV path transcribes like its 16 kHz mono equivalent."""
+    import wave
+    from oracle import whisper_oracle as wo
+    from whisper_amd import transcribe as tx
+    eng = tx.configure(model="micro", precision="fp32", max_batch=2, allow_synthetic_weights=True)
+    try:
+        rng = np.random.default_rng(11)
+        for rate in (8000, 11025, 16000, 22050, 32000, 44100, 48000, 96000):
+            for ch in (1, 2, 3):
+                for n in (1, 5, 1000, rate + 13):
+                    pcm = rng.integers(-30000, 30000, size=(n, ch), dtype=np.int16)
+                    ref = wo.resample_pcm16(pcm, rate, quantize=False)
+                    got = eng.ingest_pcm16(pcm, rate, quantize=False).cpu().numpy()
+                    assert got.shape == ref.shape
+                    assert np.abs(got - ref).max() < 4e-6, (rate, ch, n)
+                    # quantisation = round-half-even of the kernel's own fp32 value to the int16 grid, clipped (bit-exact);
+                    # against the float64 oracle that is at most one step, and only where fp32 error crosses a rounding edge
+                    gotq = eng.ingest_pcm16(pcm, rate, quantize=True).cpu().numpy()
+                    own = np.clip(np.rint(got * np.float32(32768.0)), -32768, 32767).astype(np.float32) / np.float32(32768.0)
+                    assert np.array_equal(gotq, own), (rate, ch, n)
+                    refq = wo.resample_pcm16(pcm, rate, quantize=True)
+                    assert (np.abs(gotq - refq) * 32768.0).max() <= 1.0
+        # end to end: a 44.1 kHz stereo file
+        t = np.arange(44100 * 31) / 44100.0
+        left = 0.3 * np.sin(2 * np.pi * 220 * t) + 0.02 * rng.standard_normal(t.size)
+        right = 0.2 * np.sin(2 * np.pi * 1330 * t) + 0.02 * rng.standard_normal(t.size)
+        pcm = np.clip(np.rint(np.stack([left, right], axis=1) * 32768), -32768, 32767).astype(np.int16)
+        p = str(tmp_path / "stereo44.wav")
+        with wave.open(p, "wb") as w:
+            w.setnchannels(2); w.setsampwidth(2); w.setframerate(44100); w.writeframes(pcm.tobytes())
+        a = tx.transcribe(p, language="en", max_new_tokens=8)
+        b = tx.transcribe(eng.ingest_pcm16(pcm, 44100).cpu().numpy(), language="en", max_new_tokens=8)
+        assert a["tokens"] == b["tokens"] and a["chunks_processed"] == 2
+        with pytest.raises(Exception):
+            eng.ingest_pcm16(pcm[:100], 16000 * 9)        # down > 8 * up: rejected by the C-ABI, not a fault
+    finally:
+        tx.close()
+
+
 def test_transcribe_modes_beam_and_sequential(tmp_path):
     """The north-star entry point with upstream's other decoding options: beam search and the sequential long-form loop
     return the same contract keys; chunks_processed counts decoded windows; an empty input is an empty result."""

@@ -97,6 +97,29 @@ def test_audio_helpers(tmp_path):
     assert fb.shape == (80, 201) and (fb >= 0).all() and (fb.sum(axis=1) > 0).all()
 
 
+def test_resampler_host_side(tmp_path):
+    """Rate ratios, output lengths, the numpy filter design against scipy.signal.firwin (the design scipy.signal.
+    resample_poly uses by default), and the any-WAV reader."""
+    import wave
+    import scipy.signal as ss
+    assert wa.resample_ratio(44100) == (160, 441) and wa.resample_ratio(48000) == (1, 3)
+    assert wa.resample_ratio(8000) == (2, 1) and wa.resample_ratio(16000) == (1, 1)
+    assert wa.resample_out_len(441, 160, 441) == 160 and wa.resample_out_len(442, 160, 441) == 161
+    for up, down in ((160, 441), (1, 3), (2, 1), (320, 441), (2, 3)):
+        h, half_len = wa.resample_filter(up, down)
+        ref = ss.firwin(2 * half_len + 1, 1.0 / max(up, down), window=("kaiser", 5.0)) * up
+        assert half_len == 10 * max(up, down) and h.dtype == np.float32
+        assert np.abs(h - ref).max() < 1e-7
+    h, half_len = wa.resample_filter(1, 1)            # same rate: the filter degenerates to a unit impulse
+    assert h[half_len] == 1.0 and np.abs(np.delete(h, half_len)).max() < 1e-7
+    pcm = np.random.default_rng(0).integers(-3000, 3000, size=(1234, 2), dtype=np.int16)
+    p = str(tmp_path / "s.wav")
+    with wave.open(p, "wb") as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(44100); w.writeframes(pcm.tobytes())
+    got, rate = wa.load_wav_any(p)
+    assert rate == 44100 and np.array_equal(got, pcm)
+
+
 def _fresh_dropin(monkeypatch, **env):
     for k, v in env.items():
         monkeypatch.setenv(k, v)

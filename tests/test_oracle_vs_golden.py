@@ -124,3 +124,24 @@ def test_live_against_transformers_if_available():
         la, lb = om.logits(toks, a), hf(input_features=mel, decoder_input_ids=toks).logits
     assert (a - b).abs().max() < 2e-4 * b.abs().max()
     assert (la - lb).abs().max() < 2e-4 * lb.abs().max()
+
+
+@pytest.mark.parametrize("rate", [8000, 11025, 22050, 24000, 32000, 44100, 48000, 96000])
+def test_resampler_restatement_matches_scipy(rate):
+    """The oracle's polyphase resampler (the ffmpeg normalisation step of ref:app/audio/processor.py:136-147, restated
+    with scipy.signal.resample_poly's arithmetic) against scipy itself on the same samples: within the rounding of its
+    float32 taps.  Ragged lengths, one-sample input, mono and stereo."""
+    import scipy.signal as ss
+    rng = np.random.default_rng(rate)
+    up, down = 16000 // np.gcd(16000, rate), rate // np.gcd(16000, rate)
+    for n in (1, 2, rate // 3 + 11):
+        pcm = rng.integers(-20000, 20000, size=(n, 2), dtype=np.int16)
+        mono = pcm.astype(np.float64).mean(axis=1) / 32768.0
+        ref = ss.resample_poly(mono, up, down)
+        got = wo.resample_pcm16(pcm, rate, quantize=False)
+        assert got.shape == ref.shape == (-(-n * up // down),)
+        assert np.abs(got - ref).max() < 5e-7
+        q = wo.resample_pcm16(pcm, rate, quantize=True)
+        assert np.array_equal(q * 32768.0, np.rint(q * 32768.0)) and np.abs(q - ref).max() <= 0.5 / 32768 + 5e-7
+        assert np.array_equal(wo.resample_pcm16(pcm[:, 0], rate, False), wo.resample_pcm16(pcm[:, :1], rate, False))
+

@@ -37,6 +37,7 @@ PROTOTYPES = {
     "wx_set_suppress_tokens": (c_i32, [c_vp, c_vp, c_i32]),
     "wx_finalize": (c_i32, [c_vp]),
     "wx_pcm16_to_f32": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "wx_resample_pcm16": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "wx_mel_reset_max": (c_i32, [c_vp, c_vp, c_vp]),
     "wx_mel_stage1": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "wx_mel_stage2": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),

@@ -90,6 +90,44 @@ def load_wav_pcm16_raw(path: str) -> np.ndarray:
         return np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
 
 
+def load_wav_any(path: str) -> Tuple[np.ndarray, int]:
+    """Read ANY 16-bit PCM WAV -- the input side of the reference's normaliser (ref:app/audio/processor.py:123-150) -- as
+    ``(int16 [n_frames, n_channels], sample_rate)``.  Rate conversion and the mono mix then run on the GPU
+    (``WhisperEngine.ingest_pcm16``), not in an ffmpeg subprocess."""
+    with wave.open(str(path), "rb") as w:
+        if w.getsampwidth() != 2:
+            raise ValueError(f"{path}: expected 16-bit PCM, got sample width {w.getsampwidth()}")
+        ch, rate = w.getnchannels(), w.getframerate()
+        raw = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
+    return raw.reshape(-1, ch), rate
+
+
+def resample_ratio(src_rate: int) -> Tuple[int, int]:
+    """(up, down) with up/down = 16000/src_rate in lowest terms (44100 Hz -> 160/441, 48000 Hz -> 1/3, 8000 Hz -> 2/1)."""
+    if src_rate <= 0:
+        raise ValueError("sample rate must be positive")
+    g = math.gcd(SAMPLE_RATE, int(src_rate))
+    return SAMPLE_RATE // g, int(src_rate) // g
+
+
+def resample_out_len(n_frames: int, up: int, down: int) -> int:
+    return -(-n_frames * up // down)
+
+
+def resample_filter(up: int, down: int) -> Tuple[np.ndarray, int]:
+    """Centred low-pass taps of the polyphase resampler, ``(h[2*half_len + 1] float32, half_len)``: the design
+    scipy.signal.resample_poly uses by default -- a Kaiser(beta = 5) windowed sinc with cut-off 1/max(up, down) of the
+    up-sampled Nyquist frequency, half_len = 10*max(up, down), unit DC gain, times ``up`` -- written out with numpy so
+    the product does not depend on scipy (tests/test_host_logic.py checks it against scipy.signal.firwin)."""
+    q = max(up, down)
+    half_len = 10 * q
+    k = np.arange(-half_len, half_len + 1, dtype=np.float64)
+    fc = 1.0 / q
+    h = fc * np.sinc(fc * k) * np.kaiser(2 * half_len + 1, 5.0)
+    h /= h.sum()
+    return (h * up).astype(np.float32), half_len
+
+
 def save_wav_pcm16(path: str, audio: np.ndarray) -> None:
     pcm = np.clip(np.round(np.asarray(audio, np.float64) * 32768.0), -32768, 32767).astype("<i2")
     with wave.open(str(path), "wb") as w:

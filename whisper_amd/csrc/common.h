@@ -23,6 +23,7 @@ constexpr int N_FFT = 400;
 constexpr int HOP = 160;
 constexpr int N_FREQ = 201;
 constexpr int WIN_FRAMES = 3000;  // mel frames per 30 s window
+constexpr int RS_MAX_TAPS = 65536; // resampler filter table (wx_resample_pcm16)
 
 // ---- GEMM -------------------------------------------------------------------------------------------
 // out[m][n] = epilogue( sum_k A[m][k] * W[n][k] ), A rows addressed as
@@ -102,6 +103,9 @@ int launch_mel_stage1(const MelTables& t, const float* pcm, int64_t pcm_offset, 
 int launch_mel_stage2(float* x, int64_t ld, int n_mels, int64_t n_frames, const float* d_max, hipStream_t st);
 int launch_fill_f32(float* p, float v, int64_t n, hipStream_t st);
 int launch_pcm16_to_f32(const int16_t* in, float* out, int64_t n, hipStream_t st);   // x / 32768
+// channel average + polyphase resampling of interleaved PCM16 to mono float32 (see wx_resample_pcm16); taps on the device
+int launch_resample_pcm16(const int16_t* in, int64_t n_frames, int n_channels, int up, int down, const float* d_taps,
+                          int half_len, int quantize, float* out, int64_t n_out, hipStream_t st);
 
 // ---- attention ----------------------------------------------------------------------------------------
 struct AttnArgs {

@@ -81,6 +81,7 @@ struct wx_engine {
     uint32_t* dyn = nullptr;                                 // {temperature bits, seed, sample_len} read by the sampler
     float *sum_logprob = nullptr, *no_speech = nullptr, *partial = nullptr, *gpartial = nullptr;
     int32_t* h_pinned = nullptr;
+    float* rs_taps = nullptr;                                // resampler taps (wx_resample_pcm16), RS_MAX_TAPS floats
     int encoded_B = 0;
     // beam search state (rows = windows x beams <= max_batch)
     int beam_n = 0;                      // > 0 while a beam decode is building / replaying its step
@@ -452,6 +453,7 @@ int wx_finalize(wx_engine* e) {
         if ((r = A((void**)&e->b_fin_score, (size_t)2 * B * 4))) return r;
         if ((r = A((void**)&e->b_fin_count, (size_t)B * 4))) return r;
     }
+    if ((r = A((void**)&e->rs_taps, (size_t)RS_MAX_TAPS * 4))) return r;
     HIP_TRY(hipHostMalloc((void**)&e->h_pinned, 64));
     HIP_TRY(hipDeviceSynchronize());
     e->finalized = true;
@@ -461,6 +463,23 @@ int wx_finalize(wx_engine* e) {
 int wx_pcm16_to_f32(wx_engine* e, const int16_t* d_pcm16, int64_t n, float* d_out, void* stream) {
     if (!e || !d_pcm16 || !d_out || n < 0) return fail(WX_ERR_INVALID, "bad argument");
     WX_TRY(launch_pcm16_to_f32(d_pcm16, d_out, n, (hipStream_t)stream));
+    return WX_OK;
+}
+
+int wx_resample_pcm16(wx_engine* e, const int16_t* d_pcm16, int64_t n_frames, int32_t n_channels, int32_t up, int32_t down,
+                      const float* h_taps, int32_t half_len, int32_t quantize, float* d_out, int64_t n_out, void* stream) {
+    if (!e || !e->finalized) return fail(WX_ERR_STATE, "engine not finalized");
+    if (!d_pcm16 || !h_taps || !d_out || n_frames <= 0) return fail(WX_ERR_INVALID, "bad argument");
+    if (n_channels < 1 || n_channels > 8) return fail(WX_ERR_INVALID, "n_channels must be 1..8");
+    if (up < 1 || down < 1 || down > 8 * up) return fail(WX_ERR_INVALID, "unsupported rate ratio (down <= 8*up)");
+    if (half_len < 0 || 2 * (int64_t)half_len + 1 > RS_MAX_TAPS) return fail(WX_ERR_INVALID, "too many filter taps");
+    if (n_out != (n_frames * up + down - 1) / down) return fail(WX_ERR_INVALID, "n_out must be ceil(n_frames*up/down)");
+    hipStream_t st = (hipStream_t)stream;
+    // the taps are host memory of the caller: the copy is complete when the call returns
+    HIP_TRY(hipMemcpyAsync(e->rs_taps, h_taps, (size_t)(2 * half_len + 1) * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const int r = launch_resample_pcm16(d_pcm16, n_frames, n_channels, up, down, e->rs_taps, half_len, quantize, d_out, n_out, st);
+    if (r) return fail(r == -1 ? WX_ERR_INVALID : WX_ERR_HIP, "resample launch failed (filter reach exceeds the LDS span?)");
     return WX_OK;
 }
 

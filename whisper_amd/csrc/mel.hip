@@ -168,6 +168,62 @@ int launch_pcm16_to_f32(const int16_t* in, float* out, int64_t n, hipStream_t st
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// Channel average + polyphase windowed-sinc resampling of interleaved PCM16 (any rate) to mono float32 at 16 kHz: the
+// reference's ffmpeg normalisation step done on the device, so a raw upload never takes a host pass.  One workgroup = 256
+// consecutive outputs; the input frames they touch (256*down/up + 2*half_len/up of them) are averaged over channels once
+// and staged in LDS as float (coalesced int16 reads), the taps come from a device table (<= 256 KB, L2 resident):
+//   y[n] = sum_m x[m] * h[half_len + n*down - m*up],  x = 0 outside [0, n_frames)
+// accumulated in ascending m with fmaf.  HBM bytes per output: 2*C*down/up read + 4 written.
+constexpr int RS_BLOCK = 256;
+constexpr int RS_SPAN_MAX = 6144;      // floats of LDS: 256 outputs * down/up <= 8 -> 2048 frames + 2 * half_len / up
+
+__global__ __launch_bounds__(RS_BLOCK) void resample_pcm16_kernel(const int16_t* __restrict__ in, int64_t n_frames, int C, int up,
+                                                                   int down, const float* __restrict__ taps, int half_len,
+                                                                   int quantize, float* __restrict__ out, int64_t n_out) {
+    __shared__ float s_x[RS_SPAN_MAX];
+    const int64_t n0 = (int64_t)blockIdx.x * RS_BLOCK;
+    const int64_t n1 = min(n0 + RS_BLOCK, n_out) - 1;                        // last output of this block
+    // m range of one output n: ceil((n*down - half_len) / up) .. floor((n*down + half_len) / up)
+    auto m_first = [&](int64_t n) { const int64_t a = n * down - half_len; return a >= 0 ? (a + up - 1) / up : -((-a) / up); };
+    auto m_last = [&](int64_t n) { const int64_t a = n * down + half_len; return a / up; };
+    const int64_t mb = m_first(n0), me = m_last(n1);
+    const int span = (int)(me - mb + 1);
+    const float inv = 1.0f / (32768.0f * (float)C);
+    for (int i = threadIdx.x; i < span; i += RS_BLOCK) {
+        const int64_t m = mb + i;
+        float v = 0.f;
+        if (m >= 0 && m < n_frames) {
+            int acc = 0;
+            for (int c = 0; c < C; ++c) acc += in[m * C + c];
+            v = (float)acc * inv;
+        }
+        s_x[i] = v;
+    }
+    __syncthreads();
+    const int64_t n = n0 + threadIdx.x;
+    if (n >= n_out) return;
+    const int64_t lo = m_first(n), hi = m_last(n);
+    float y = 0.f;
+    int idx = (int)(half_len + n * down - lo * up);                        // tap index of the first input frame
+    for (int64_t m = lo; m <= hi; ++m, idx -= up) y = fmaf(s_x[m - mb], taps[idx], y);
+    if (quantize) y = fminf(fmaxf(rintf(y * 32768.0f), -32768.0f), 32767.0f) * (1.0f / 32768.0f);
+    out[n] = y;
+}
+
+int launch_resample_pcm16(const int16_t* in, int64_t n_frames, int n_channels, int up, int down, const float* d_taps,
+                          int half_len, int quantize, float* out, int64_t n_out, hipStream_t st) {
+    if (n_out <= 0) return 0;
+    if (n_frames <= 0 || n_channels < 1 || n_channels > 8 || up < 1 || down < 1 || down > 8 * up || half_len < 0) return -1;
+    if (n_out != (n_frames * up + down - 1) / down) return -1;
+    // LDS span of one block: frames under 256 outputs plus the filter's reach on either side
+    const int64_t span = ((int64_t)(RS_BLOCK - 1) * down + 2 * (int64_t)half_len) / up + 3;
+    if (span > RS_SPAN_MAX) return -1;
+    const int64_t blocks = (n_out + RS_BLOCK - 1) / RS_BLOCK;
+    hipLaunchKernelGGL(resample_pcm16_kernel, dim3((unsigned)blocks), dim3(RS_BLOCK), 0, st, in, n_frames, n_channels, up, down,
+                       d_taps, half_len, quantize, out, n_out);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 __global__ void fill_f32_kernel(float* p, float v, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }

@@ -105,6 +105,29 @@ class WhisperEngine:
         _lib.check(self.lib.wx_pcm16_to_f32(self.handle, _ptr(t), t.numel(), _ptr(out), self._stream()), "wx_pcm16_to_f32")
         return out
 
+    def ingest_pcm16(self, pcm16, src_rate: int, quantize: bool = True) -> torch.Tensor:
+        """Interleaved int16 PCM ``[n_frames]`` or ``[n_frames, n_channels]`` at ``src_rate`` -> mono float32 at 16 kHz on
+        the device: channel average + polyphase resampling in one HIP kernel (``wx_resample_pcm16``), the reference's
+        ffmpeg normalisation (ref:app/audio/processor.py:136-147) without the subprocess.  ``quantize`` rounds to the
+        int16 grid like the intermediate s16le WAV of the reference does."""
+        from .audio import resample_filter, resample_out_len, resample_ratio
+        t = torch.from_numpy(np.array(pcm16, copy=True)) if not torch.is_tensor(pcm16) else pcm16
+        if t.dtype != torch.int16 or t.dim() not in (1, 2):
+            raise ValueError("ingest_pcm16 expects int16 samples, [n_frames] or [n_frames, n_channels]")
+        n_frames, ch = int(t.shape[0]), (int(t.shape[1]) if t.dim() == 2 else 1)
+        if n_frames == 0:
+            return torch.empty(0, dtype=torch.float32, device=self.torch_device)
+        up, down = resample_ratio(int(src_rate))
+        if up == 1 and down == 1 and ch == 1:
+            return self.pcm16_to_f32(t.reshape(-1))
+        taps, half_len = resample_filter(up, down)
+        n_out = resample_out_len(n_frames, up, down)
+        t = t.to(self.torch_device).contiguous()
+        out = torch.empty(n_out, dtype=torch.float32, device=self.torch_device)
+        _lib.check(self.lib.wx_resample_pcm16(self.handle, _ptr(t), n_frames, ch, up, down, taps.ctypes.data, half_len,
+                                              1 if quantize else 0, _ptr(out), n_out, self._stream()), "wx_resample_pcm16")
+        return out
+
     # -- mel ----------------------------------------------------------------------------------------------
     def mel_stage1(self, pcm: torch.Tensor, pcm_offset: int, n_file: int, n_total: int, frame0: int, n_frames: int,
                    out: torch.Tensor, gmax: torch.Tensor) -> None:

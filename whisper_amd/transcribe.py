@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import checkpoint as ck
-from .audio import N_FRAMES, N_SAMPLES, load_wav_pcm16, load_wav_pcm16_raw
+from .audio import N_FRAMES, N_SAMPLES, SAMPLE_RATE, load_wav_any
 from .tokenizer import LANGUAGE_CODES, Tokenizer, language_index
 
 logger = logging.getLogger(__name__)
@@ -78,10 +78,12 @@ def get_tokenizer() -> Tokenizer:
 
 def _load_audio(audio: Union[str, Path, np.ndarray, torch.Tensor]) -> np.ndarray:
     if isinstance(audio, (str, Path)):
-        try:
-            return load_wav_pcm16_raw(str(audio))     # int16: uploaded as is, /32768 on the GPU
-        except ValueError:
-            return load_wav_pcm16(str(audio))         # multi-channel: averaged on the host
+        pcm, rate = load_wav_any(str(audio))
+        if rate == SAMPLE_RATE and pcm.shape[1] == 1:
+            return np.ascontiguousarray(pcm[:, 0])    # int16: uploaded as is, /32768 on the GPU
+        # any other rate / channel count: the reference's ffmpeg normalisation, done on the device
+        # (ref:app/audio/processor.py:136-147); the 16 kHz mono result comes back as the host array the sharding needs
+        return get_engine().ingest_pcm16(pcm, rate).cpu().numpy()
     if torch.is_tensor(audio):
         audio = audio.detach().cpu().numpy()
     a = np.asarray(audio)
