@@ -135,6 +135,11 @@ def test_properties_at_scale_bf16():
         eng.encode(view, 3000, mel.stride(0), content - 4 * 3000, 4)
         c = eng.decode_greedy(4, init, max_new_tokens=24)
         assert torch.equal(c["tokens"].cpu(), ta[4:8])
+        # ... and so does a single window (other encoder GEMM tile shape, one decode row): nothing in the engine may make a
+        # window's ids depend on its batch -- the cross-attention key split is a function of max_batch, not of B
+        eng.encode(mel[:, 9 * 3000:], 3000, mel.stride(0), content - 9 * 3000, 1)
+        one = eng.decode_greedy(1, init, max_new_tokens=24)
+        assert torch.equal(one["tokens"].cpu(), ta[9:10])
         for r in range(16):
             assert (ta[r, len(init) + int(na[r]):] == eng.tok.eot).all()
         # the same clip at a different position of the file has the same mel (only the clamp is global)

@@ -66,6 +66,26 @@ def test_mel_parity(models, n_mels, n_samples):
     assert rel_err(got, ref) < 1e-4
 
 
+def test_mel_with_a_dense_caller_supplied_filterbank():
+    """A filterbank with more non-zero weights than the kernel keeps in LDS (any [n_mels, 201] matrix may be supplied, e.g.
+    upstream's mel_filters.npz) takes the kernel's global-memory weight path: same result as the plain formula."""
+    from whisper_amd.engine import WhisperEngine
+    dims = ck.dims_for("micro")
+    fb = np.abs(np.random.default_rng(2).standard_normal((dims.n_mels, 201))).astype(np.float32) * 0.01
+    eng = WhisperEngine(dims, ck.synthetic_state_dict(dims, seed=0), precision="fp32", max_batch=1, mel_filters=fb)
+    try:
+        audio = wo.synthetic_audio(4, 16000 * 7 + 5)
+        x = torch.from_numpy(np.concatenate([audio, np.zeros(wo.N_SAMPLES, np.float32)]))
+        st = torch.stft(x, 400, 160, window=torch.hann_window(400), return_complex=True)
+        mel = torch.from_numpy(fb).double() @ (st[:, :-1].abs().double() ** 2)
+        lg = torch.clamp(mel, min=1e-10).log10()
+        ref = ((torch.maximum(lg, lg.max() - 8.0) + 4.0) / 4.0).numpy()
+        got = eng.log_mel(torch.from_numpy(audio)).cpu().numpy()
+        assert got.shape == ref.shape and rel_err(got, ref) < 1e-4
+    finally:
+        eng.close()
+
+
 def test_mel_two_stage_matches_sharded_max(models):
     """Stage 1 on two halves + MAX of the two maxima + stage 2 == single pass (SURVEY.md §8e caveat 1)."""
     dims, sd, eng = models("micro", "fp32")

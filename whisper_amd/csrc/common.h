@@ -93,9 +93,9 @@ int launch_zero_pad_rows(void* xpad, int dt, int B, int rows_per_batch, int C, h
 struct MelTables {                       // device tables built at wx_finalize
     const float* window = nullptr;       // [400] periodic Hann
     const float* cs = nullptr;           // [400][2] cos, sin of 2*pi*i/400
-    const float* filters = nullptr;      // [n_mels][201]
-    const int32_t* frange = nullptr;     // [n_mels][2] first/last+1 non-zero bin of each filter
-    int n_mels = 0;
+    const float* filters = nullptr;      // packed non-zero runs of the [n_mels][201] filterbank, n_pack floats
+    const int32_t* frange = nullptr;     // [n_mels][4]: first / last+1 non-zero bin of each filter, offset of its run, 0
+    int n_mels = 0, n_pack = 0;
 };
 int launch_mel_stage1(const MelTables& t, const float* pcm, int64_t pcm_offset, int64_t n_valid, int64_t n_file,
                       int64_t n_total, int64_t frame0, int64_t n_frames, float* out, int64_t ld, float* d_max,

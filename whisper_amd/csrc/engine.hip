@@ -372,19 +372,24 @@ int wx_finalize(wx_engine* e) {
             cs[2 * i] = (float)cos(2.0 * M_PI * i / N_FFT);
             cs[2 * i + 1] = (float)sin(2.0 * M_PI * i / N_FFT);
         }
-        std::vector<int32_t> fr(c.n_mels * 2);
+        // sparse filterbank: per mel bin {first non-zero DFT bin, last + 1, offset of its weights in the packed table, 0}
+        std::vector<int32_t> fr((size_t)c.n_mels * 4, 0);
+        std::vector<float> pack;
         for (int m = 0; m < c.n_mels; ++m) {
             int lo = N_FREQ, hi = 0;
             for (int k = 0; k < N_FREQ; ++k) if (e->mel_filters_h[(size_t)m * N_FREQ + k] != 0.f) { if (k < lo) lo = k; hi = k + 1; }
             if (lo > hi) lo = hi = 0;
-            fr[2 * m] = lo; fr[2 * m + 1] = hi;
+            fr[4 * m] = lo; fr[4 * m + 1] = hi; fr[4 * m + 2] = (int32_t)pack.size();
+            for (int k = lo; k < hi; ++k) pack.push_back(e->mel_filters_h[(size_t)m * N_FREQ + k]);
         }
+        if (pack.empty()) pack.push_back(0.f);
         float *w, *t, *f; void* fp;
         if ((r = upload_f32(e, win.data(), win.size(), &w))) return r;
         if ((r = upload_f32(e, cs.data(), cs.size(), &t))) return r;
-        if ((r = upload_f32(e, e->mel_filters_h.data(), e->mel_filters_h.size(), &f))) return r;
+        if ((r = upload_f32(e, pack.data(), pack.size(), &f))) return r;
         if ((r = dev_alloc(e, &fp, fr.size() * 4, true))) return r;
         HIP_TRY(hipMemcpy(fp, fr.data(), fr.size() * 4, hipMemcpyHostToDevice));
+        e->mel.n_pack = (int)pack.size();
         e->mel.window = w; e->mel.cs = t; e->mel.filters = f; e->mel.frange = (const int32_t*)fp; e->mel.n_mels = c.n_mels;
     }
     {
@@ -608,6 +613,17 @@ static void set_self_cache(const wx_engine* e, AttnArgs& a, int b0) {
 
 // one decoder step for position *d_pos (all launches read the position from device memory -> graph-replayable)
 // fp32 ("token-exact") sequence: every GEMM applies its own epilogue, LayerNorm is a separate kernel.
+// Key split of the decoder cross-attention (workgroups per (window, head)).  A function of the ENGINE (max_batch, beam
+// width), never of the batch at hand: the split fixes the order in which partial softmax states are merged, so with a
+// per-call choice a window's bf16 logits -- and at a near-tie its token ids -- would depend on how many other windows
+// happened to share its batch.
+static int cross_attn_key_split(const wx_engine* e) {
+    const int windows = e->cfg.max_batch / (e->beam_n > 0 ? e->beam_n : 1);
+    int n_split = 1;
+    while (n_split < 6 && (windows > 0 ? windows : 1) * e->Ht * n_split < 512) ++n_split;
+    return n_split;
+}
+
 static int decode_step_f32(wx_engine* e, int B, const SamplerArgs* sa, hipStream_t st) {
     const int d = e->d, dtp = e->dt, T = e->T;
     const size_t es = dtype_size(dtp);
@@ -615,8 +631,7 @@ static int decode_step_f32(wx_engine* e, int B, const SamplerArgs* sa, hipStream
     WX_TRY(launch_embed(e->tok_emb, e->dec_pos, dtp, e->tokens, c.n_text_ctx, e->d_pos, e->dx, B, d, st));
     const size_t cross_layer = (size_t)c.max_batch * e->Ht * T * HEAD_DIM;
     const size_t self_layer = (size_t)c.max_batch * e->n_pages_seq * e->Ht * KV_PAGE * HEAD_DIM;
-    int n_split = 1;
-    while (n_split < 6 && (B / (e->beam_n > 0 ? e->beam_n : 1)) * e->Ht * n_split < 512) ++n_split;
+    const int n_split = cross_attn_key_split(e);
     for (int i = 0; i < c.n_text_layer; ++i) {
         const LayerW& L = e->dec[i];
         WX_TRY(launch_layernorm(e->dx, L.ln1_g, L.ln1_b, e->dxn, dtp, B, d, st));
@@ -700,8 +715,7 @@ static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, floa
     WX_TRY(launch_embed(e->tok_emb, e->dec_pos, dtp, e->tokens + (size_t)b0 * c.n_text_ctx, c.n_text_ctx, e->d_pos, dx, B, d, st));
     const size_t cross_layer = (size_t)c.max_batch * e->Ht * T * HEAD_DIM, cross_b0 = (size_t)b0 * e->Ht * T * HEAD_DIM;
     const size_t self_layer = (size_t)c.max_batch * e->n_pages_seq * e->Ht * KV_PAGE * HEAD_DIM;
-    int n_split = 1;
-    while (n_split < 6 && (B / (e->beam_n > 0 ? e->beam_n : 1)) * e->Ht * n_split < 512) ++n_split;
+    const int n_split = cross_attn_key_split(e);
     // tuning hooks (WX_SPLIT_DD / FC2 / QKV / FC1 override the K-split of the four decode GEMM shapes)
     static const int o_dd = getenv("WX_SPLIT_DD") ? atoi(getenv("WX_SPLIT_DD")) : 0, o_fc2 = getenv("WX_SPLIT_FC2") ? atoi(getenv("WX_SPLIT_FC2")) : 0,
                      o_qkv = getenv("WX_SPLIT_QKV") ? atoi(getenv("WX_SPLIT_QKV")) : 0, o_fc1 = getenv("WX_SPLIT_FC1") ? atoi(getenv("WX_SPLIT_FC1")) : 0;

@@ -32,7 +32,10 @@ def _ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
 
 class WhisperEngine:
     def __init__(self, dims: ModelDims, state_dict: Dict[str, torch.Tensor], precision: str = "bf16",
-                 max_batch: int = 8, device: int = 0, suppress_ids: Optional[Sequence[int]] = None):
+                 max_batch: int = 8, device: int = 0, suppress_ids: Optional[Sequence[int]] = None,
+                 mel_filters: Optional[np.ndarray] = None):
+        """``mel_filters``: optional ``[n_mels, 201]`` float32 filterbank (e.g. the array of upstream's
+        ``assets/mel_filters.npz``); default: the Slaney bank computed by ``audio.slaney_mel_filterbank``."""
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
         if not torch.cuda.is_available():
@@ -59,7 +62,9 @@ class WhisperEngine:
                 shape = (ctypes.c_int64 * a.ndim)(*a.shape)
                 _lib.check(self.lib.wx_set_weight(self.handle, name.encode(), a.ctypes.data_as(ctypes.c_void_p), shape, a.ndim),
                            f"wx_set_weight({name})")
-            fb = np.ascontiguousarray(slaney_mel_filterbank(dims.n_mels))
+            fb = np.ascontiguousarray(slaney_mel_filterbank(dims.n_mels) if mel_filters is None else mel_filters, dtype=np.float32)
+            if fb.shape != (dims.n_mels, 201):
+                raise ValueError(f"mel_filters must be [{dims.n_mels}, 201]")
             _lib.check(self.lib.wx_set_mel_filters(self.handle, fb.ctypes.data_as(ctypes.c_void_p)), "wx_set_mel_filters")
             self.suppress_ids = list(default_suppress_ids(t) if suppress_ids is None else suppress_ids)
             sup = np.asarray(self.suppress_ids, np.int32)
