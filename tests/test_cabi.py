@@ -25,6 +25,33 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.PROTOTYPES) == names, "whisper_amd/_lib.py prototypes must mirror the header one-to-one"
 
 
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/whisper_amd.h is what another host language binds: it must compile as C99 with no C++ or HIP types, and a C
+    program linked against the library must reach the entry points (argument errors only -- no GPU here)."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "cabi.c"
+    src.write_text(
+        '#include "whisper_amd.h"\n#include <stdio.h>\n#include <string.h>\n'
+        'int main(void) {\n'
+        '  wx_config cfg; memset(&cfg, 0, sizeof cfg);\n'
+        '  wx_engine* e = 0;\n'
+        '  if (!strstr(wx_version(), "gfx950")) return 1;\n'
+        '  if (wx_create(0, &e) >= 0) return 2;\n'
+        '  if (wx_create(&cfg, &e) >= 0) return 3;          /* all-zero dims are rejected before any HIP call */\n'
+        '  if (wx_finalize(0) >= 0) return 4;\n'
+        '  if (sizeof(wx_config) != 23 * 4 || sizeof(wx_decode_opts) != 9 * 4) return 5;\n'
+        '  printf("%s\\n", wx_last_error());\n  return 0;\n}\n')
+    exe = tmp_path / "cabi"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src),
+                    "-L", libdir, "-lwhisper_amd", "-Wl,-rpath," + libdir, "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+
+
 def test_struct_layouts_match_header():
     src = open(os.path.join(ROOT, "include", "whisper_amd.h")).read()
     cfg = re.search(r"typedef struct \{([^}]*)\} wx_config;", src).group(1)
