@@ -263,6 +263,31 @@ def test_bf16_greedy_agrees_with_oracle_where_margin_is_large(models):
             assert int(t[b, len(init) + i]) == want
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_more_than_64_rows_take_the_general_decode_path(models, precision):
+    """The split-K decode kernels serve batches of up to 64 rows; a larger batch runs the general GEMM / attention kernels.
+    72 windows at once: fp32 ids equal the oracle's, bf16 ids agree wherever the oracle's top-2 margin is comfortable."""
+    dims, sd, eng = models("micro", precision, max_batch=72, eot_boost=3.0)
+    om = wo.OracleWhisper(dims, sd)
+    tok = eng.tok
+    mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(100 + s, 16000 * 3), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000]
+                        for s in range(72)])
+    init = wo.initial_tokens(tok, 0)
+    with torch.no_grad():
+        ref = wo.greedy_decode(om, om.encode(mels), init, tok, wo.suppress_token_ids(tok, ck.non_speech_suppress_ids()), max_new_tokens=10)
+    eng.encode_windows(mels)
+    r = eng.decode_greedy(72, init, max_new_tokens=10)
+    t, n = r["tokens"].cpu(), r["n_tokens"].cpu()
+    for b in range(72):
+        if precision == "fp32":
+            assert t[b, len(init):len(init) + int(n[b])].tolist() == ref["tokens"][b]
+        else:
+            for i, want in enumerate(ref["tokens"][b]):
+                if ref["margins"][i, b] < 0.15:
+                    break
+                assert int(t[b, len(init) + i]) == want
+
+
 @pytest.mark.parametrize("name,beam,boost,use_graph", [("micro", 5, 3.0, True), ("micro", 5, 6.0, False), ("tiny", 3, 3.0, True),
                                                      ("micro", 8, 6.0, True)])
 def test_beam_search_matches_oracle_fp32(models, name, beam, boost, use_graph):
