@@ -263,22 +263,23 @@ def test_bf16_greedy_agrees_with_oracle_where_margin_is_large(models):
             assert int(t[b, len(init) + i]) == want
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_more_than_64_rows_take_the_general_decode_path(models, precision):
-    """The split-K decode kernels serve batches of up to 64 rows; a larger batch runs the general GEMM / attention kernels.
-    72 windows at once: fp32 ids equal the oracle's, bf16 ids agree wherever the oracle's top-2 margin is comfortable."""
-    dims, sd, eng = models("micro", precision, max_batch=72, eot_boost=3.0)
+@pytest.mark.parametrize("precision,rows", [("fp32", 96), ("bf16", 72), ("bf16", 80), ("bf16", 96)])
+def test_large_decode_batches(models, precision, rows):
+    """The split-K decode kernels serve batches of up to 80 rows (5 MFMA row tiles: 64 greedy windows, or 15 windows x 5
+    beams); a larger batch runs the general GEMM / attention kernels.  fp32 ids equal the oracle's, bf16 ids agree wherever
+    the oracle's top-2 margin is comfortable."""
+    dims, sd, eng = models("micro", precision, max_batch=rows, eot_boost=3.0)
     om = wo.OracleWhisper(dims, sd)
     tok = eng.tok
     mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(100 + s, 16000 * 3), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000]
-                        for s in range(72)])
+                        for s in range(rows)])
     init = wo.initial_tokens(tok, 0)
     with torch.no_grad():
         ref = wo.greedy_decode(om, om.encode(mels), init, tok, wo.suppress_token_ids(tok, ck.non_speech_suppress_ids()), max_new_tokens=10)
     eng.encode_windows(mels)
-    r = eng.decode_greedy(72, init, max_new_tokens=10)
+    r = eng.decode_greedy(rows, init, max_new_tokens=10)
     t, n = r["tokens"].cpu(), r["n_tokens"].cpu()
-    for b in range(72):
+    for b in range(rows):
         if precision == "fp32":
             assert t[b, len(init):len(init) + int(n[b])].tolist() == ref["tokens"][b]
         else:
@@ -335,6 +336,14 @@ def test_beam_search_bf16_shares_cross_kv(models):
     assert b1["tokens"] == greedy
     b5 = eng.decode_beam(3, init, beam_size=5, max_new_tokens=16)
     assert len(b5["tokens"]) == 3 and all(len(c) >= 5 for c in b5["candidates"])
+    # 15 windows x 5 beams = 75 rows (BASELINE configs[3] per GPU) in one batch: the windows that were also decoded in the
+    # batch of 3 keep their result (batch invariance holds for beam search too: same key split, same GEMM k order)
+    dims2, sd2, eng75 = models("micro256", "bf16", max_batch=75, attn_gain=1.0, eot_boost=3.0)
+    mels15 = torch.cat([mels] + [torch.stack([wo.log_mel_spectrogram(wo.varied_audio(40 + s, 16000 * 5), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000]
+                                              for s in range(12)])])
+    eng75.encode_windows(mels15)
+    b75 = eng75.decode_beam(15, init, beam_size=5, max_new_tokens=16)
+    assert len(b75["tokens"]) == 15 and b75["tokens"][:3] == b5["tokens"]
     for b in range(3):     # the best beam can only score at least as well as the greedy path under the same model
         assert max(c[1] / max(len(c[0]), 1) for c in b5["candidates"][b]) >= g["sum_logprobs"].cpu()[b].item() / max(len(greedy[b]), 1) - 1e-2
 

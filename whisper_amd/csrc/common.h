@@ -24,6 +24,8 @@ constexpr int HOP = 160;
 constexpr int N_FREQ = 201;
 constexpr int WIN_FRAMES = 3000;  // mel frames per 30 s window
 constexpr int RS_MAX_TAPS = 65536; // resampler filter table (wx_resample_pcm16)
+constexpr int DG_MAX_ROWS = 80;    // rows served by the split-K decode GEMM path (5 MFMA row tiles): 64 greedy windows, or
+                                   // 15 windows x 5 beams (BASELINE configs[3]: 120 windows of a 1 h file over 8 GPUs)
 
 // ---- GEMM -------------------------------------------------------------------------------------------
 // out[m][n] = epilogue( sum_k A[m][k] * W[n][k] ), A rows addressed as
@@ -58,7 +60,7 @@ struct GemmArgs {
     int64_t ldw = 0;
     int M = 0, N = 0, K = 0;
     int in_dtype = DT_F32;              // dtype of A and W
-    // bf16, M <= 64 only: split K over n_split workgroups; raw fp32 partial tiles go to partial[split][M][N] and the
+    // bf16, M <= DG_MAX_ROWS only: split K over n_split workgroups; raw fp32 partial tiles go to partial[split][M][N] and the
     // epilogue is NOT applied (the consumer adds the partials, bias, scale, residual itself)
     int n_split = 1;
     float* partial = nullptr;
@@ -66,7 +68,7 @@ struct GemmArgs {
 };
 // Returns 0 or a negative wx_status. Chooses the kernel from (dtype, M).
 int launch_gemm(const GemmArgs& g, hipStream_t st);
-// K-split factor that fills the chip for a bf16 decode GEMM (M <= 64) whose consumer can add partial tiles; 1 = none.
+// K-split factor that fills the chip for a bf16 decode GEMM (M <= DG_MAX_ROWS) whose consumer can add partial tiles; 1 = none.
 int decode_gemm_split(int N, int K);
 
 // ---- elementwise / norms ---------------------------------------------------------------------------

@@ -700,7 +700,7 @@ static int decode_step_f32(wx_engine* e, int B, const SamplerArgs* sa, hipStream
     return 0;
 }
 
-// bf16 sequence (rows [b0, b0 + B) of the batch, B <= 64): the q|k|v projection, the three residual GEMMs of a layer and
+// bf16 sequence (rows [b0, b0 + B) of the batch, B <= DG_MAX_ROWS): the q|k|v projection, the three residual GEMMs of a layer and
 // the cross-attention query projection split K over workgroups and hand raw fp32 partial tiles to their consumer -- the
 // next LayerNorm (reduce + bias + residual + LN in one kernel) or the attention kernel's q/k/v load -- so every weight
 // byte streams once with the whole chip pulling, and no launch is added.  11 launches per layer.
@@ -789,7 +789,7 @@ static int decode_step_bf16(wx_engine* e, int B, const SamplerArgs* sa, hipStrea
 
 // decoder layers for B rows at position *d_pos, then the greedy sampler (sa) or nothing (the beam step follows)
 static int decode_step(wx_engine* e, int B, const SamplerArgs* sa, hipStream_t st) {
-    return (e->dt == DT_BF16 && B <= 64) ? decode_step_bf16(e, B, sa, st) : decode_step_f32(e, B, sa, st);
+    return (e->dt == DT_BF16 && B <= DG_MAX_ROWS) ? decode_step_bf16(e, B, sa, st) : decode_step_f32(e, B, sa, st);
 }
 
 static SamplerArgs make_sampler(wx_engine* e, int B, const wx_decode_opts& o, int forced) {

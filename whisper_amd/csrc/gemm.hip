@@ -3,7 +3,7 @@
 // Three kernels, one epilogue:
 //   gemm_bf16_tile   128x128x64 block tile, 4 waves (2x2), v_mfma_f32_16x16x32_bf16, XOR-swizzled LDS image,
 //                    register-staged prefetch of the next K tile.  Encoder GEMMs (M = B*1500).       [MFMA-bound]
-//   gemm_bf16_decode M <= 64 decode GEMMs: weights stream once from HBM straight to VGPRs, the activation slice is
+//   gemm_bf16_decode M <= 80 decode GEMMs: weights stream once from HBM straight to VGPRs, the activation slice is
 //                    shared through LDS, optional split-K with consumer-side reduction.     [HBM/latency-bound]
 //   gemm_f32_tile    fp32 "token-exact" mode on v_mfma_f32_16x16x4_f32 (bitwise a k-ordered fmaf chain).
 // The MFMA operands are swapped (W is the A operand, the activation the B operand) so each lane ends up with 4
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_tile256_kernel(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// bf16 decode GEMM (M <= 64): the weight matrix is read exactly once, straight from HBM to VGPRs as the MFMA A operand.
+// bf16 decode GEMM (M <= DG_MAX_ROWS = 80): the weight matrix is read exactly once, straight from HBM to VGPRs as the MFMA A operand.
 // A decode step at batch 64 reads 3-13 MB per GEMM: less than one HBM round trip per CU, so the kernel is built around
 // latency, not bandwidth:
 //   * one workgroup = 4 waves = 64 output columns (16 per wave) x all M rows x one K slice [split*Kb, (split+1)*Kb);
@@ -576,15 +576,16 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
     if (g.in_dtype == DT_BF16) {
         const int kb = (g.n_split >= 1 && g.K % g.n_split == 0) ? g.K / g.n_split : 0;
         const int cks = kb ? decode_gemm_cks(kb) : 0;
-        if (g.n_split > 1 && (!cks || !g.partial || g.M > 64 || g.a_rows_per_batch != 0)) return -1;
-        if (g.M <= 64 && g.a_rows_per_batch == 0 && cks) {
+        if (g.n_split > 1 && (!cks || !g.partial || g.M > DG_MAX_ROWS || g.a_rows_per_batch != 0)) return -1;
+        if (g.M <= DG_MAX_ROWS && g.a_rows_per_batch == 0 && cks) {
             const int blocks = ((g.N + DG_BN - 1) / DG_BN) * g.n_split, nch = kb / (cks * 32);
             bool ok;
             switch ((g.M + 15) / 16) {
                 case 1: ok = launch_decode_mt<1>(g, cks, nch, blocks, st); break;
                 case 2: ok = launch_decode_mt<2>(g, cks, nch, blocks, st); break;
                 case 3: ok = launch_decode_mt<3>(g, cks, nch, blocks, st); break;
-                default: ok = launch_decode_mt<4>(g, cks, nch, blocks, st); break;
+                case 4: ok = launch_decode_mt<4>(g, cks, nch, blocks, st); break;
+                default: ok = launch_decode_mt<5>(g, cks, nch, blocks, st); break;
             }
             if (!ok) return -1;
         } else {
