@@ -215,6 +215,44 @@ def test_resample_ingest_matches_oracle(tmp_path):
         tx.close()
 
 
+def test_cabi_rejects_bad_calls_and_stays_usable():
+    """Error behaviour at the C-ABI on a live engine: every misuse returns a negative status with a message (nothing
+    throws, nothing is launched), and the engine still decodes afterwards."""
+    from oracle import whisper_oracle as wo
+    from whisper_amd import _lib
+    from whisper_amd.engine import WhisperEngine
+    dims = ck.dims_for("micro")
+    eng = WhisperEngine(dims, ck.synthetic_state_dict(dims, 0, eot_boost=3.0), precision="fp32", max_batch=4)
+    try:
+        init = eng.initial_tokens(0)
+        with pytest.raises(_lib.WxError, match="wx_encode"):          # decode before any encode
+            eng.decode_greedy(1, init, max_new_tokens=4)
+        mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(s), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000] for s in range(2)])
+        with pytest.raises(_lib.WxError, match="max_batch"):
+            eng.encode(torch.zeros((5, dims.n_mels, 3000), device="cuda"), dims.n_mels * 3000, 3000, 5 * 3000, 5)
+        eng.encode_windows(mels)
+        good = eng.decode_greedy(2, init, max_new_tokens=6)["tokens"].cpu()
+        with pytest.raises(_lib.WxError):                              # more rows than were encoded
+            eng.decode_greedy(3, init, max_new_tokens=4)
+        with pytest.raises(_lib.WxError, match="out of range"):
+            eng.decode_greedy(2, init[:-1] + [dims.n_vocab + 7], max_new_tokens=4)
+        with pytest.raises(_lib.WxError):                              # prompt as long as the text context
+            eng.decode_greedy(2, [eng.tok.sot] * dims.n_text_ctx, max_new_tokens=4)
+        with pytest.raises((_lib.WxError, ValueError)):                # 2 windows x 5 beams > max_batch 4
+            eng.decode_beam(2, init, beam_size=5, max_new_tokens=4)
+        with pytest.raises(_lib.WxError):                              # negative temperature
+            eng.decode_rows([init, init], temperature=-1.0, max_new_tokens=4)
+        out = torch.empty((dims.n_mels, 10), device="cuda"); g = torch.empty(1, device="cuda")
+        pcm = torch.zeros(16000, device="cuda")
+        rc = eng.lib.wx_mel_stage1(eng.handle, pcm.data_ptr(), 0, 16000, 16000, 16000 + 480000, 0, 100, out.data_ptr(), 10, g.data_ptr(), None)
+        assert rc < 0 and b"mel" in eng.lib.wx_last_error()           # ld < n_frames
+        assert eng.lib.wx_decode_greedy(eng.handle, 2, None, None, None, None, None, None, None, None) < 0
+        again = eng.decode_greedy(2, init, max_new_tokens=6)["tokens"].cpu()
+        assert torch.equal(good, again)
+    finally:
+        eng.close()
+
+
 def test_transcribe_modes_beam_and_sequential(tmp_path):
     """The north-star entry point with upstream's other decoding options: beam search and the sequential long-form loop
     return the same contract keys; chunks_processed counts decoded windows; an empty input is an empty result."""
