@@ -348,6 +348,33 @@ def test_beam_search_bf16_shares_cross_kv(models):
         assert max(c[1] / max(len(c[0]), 1) for c in b5["candidates"][b]) >= g["sum_logprobs"].cpu()[b].item() / max(len(greedy[b]), 1) - 1e-2
 
 
+def test_prompt_pass_is_bit_identical_to_stepwise_feeding_bf16(models, monkeypatch):
+    """bf16 decode feeds the forced part of the prompts several positions per pass (rows = sequences x positions).  With
+    previous-text prompts of different lengths (SOT in the middle of the row, so the no-speech read falls inside a pass),
+    ids, cumulative log-probabilities and no-speech probabilities are bit-identical to one-position-per-step feeding."""
+    dims, sd, eng = models("micro256", "bf16", max_batch=16, attn_gain=1.0, eot_boost=3.0)
+    tok = eng.tok
+    rng = np.random.default_rng(8)
+    mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(60 + s), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000] for s in range(3)])
+    eng.encode_windows(mels)
+    prompts = [eng.initial_tokens(0, prompt_ids=[int(x) for x in rng.integers(0, tok.eot, size=n)]) for n in (37, 60, 19)]
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("WX_NO_PREFILL", flag)
+        for temperature in (0.0, 0.7):
+            r = eng.decode_rows(prompts, temperature=temperature, seed=5, max_new_tokens=12)
+            outs.append((r["tokens"], [float(x) for x in r["sum_logprobs"]], [float(x) for x in r["no_speech_probs"]]))
+    assert outs[0] == outs[2] and outs[1] == outs[3]
+    assert all(len(t) > 0 for t in outs[0][0]) and all(0.0 < p < 1.0 for p in outs[0][2])
+    # the same through the shared-prompt entry point (default 4-id prompt: three forced positions, one pass)
+    g = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("WX_NO_PREFILL", flag)
+        r = eng.decode_greedy(3, wo.initial_tokens(tok, 0), max_new_tokens=12)
+        g.append((r["tokens"].cpu(), r["sum_logprobs"].cpu(), r["no_speech_probs"].cpu()))
+    assert all(torch.equal(a, b) for a, b in zip(g[0], g[1]))
+
+
 def test_sequential_long_form_matches_oracle_fp32(models):
     """Upstream's sequential loop (timestamps, previous-text prompt, timestamp-driven seek) at temperature 0: two files of
     different length decoded in lockstep (one batch per iteration, per-row prompts) give, file by file, the oracle's

@@ -114,10 +114,14 @@ __global__ __launch_bounds__(64 * HPB * NWH) void attn_self_decode_kernel(AttnAr
     if (!valid) bh = a.B * a.H - 1;
     const int b = bh / a.H, h = bh % a.H;
     const int sub = lane % LPK, grp = lane / LPK;
-    const int t_cur = *a.d_pos, n_keys = t_cur + 1;
+    // prompt pass (q_group > 1): row b is position *d_pos + b % q_group of sequence b / q_group, whose k/v rows are already
+    // in the cache (launch_kv_append ran first): nothing is appended or patched here
+    const bool single = a.q_group == 1;
+    const int seq = b / a.q_group;
+    const int t_cur = *a.d_pos + b % a.q_group, n_keys = t_cur + 1;
     const int PS = a.page_size;
     if (kw == 0) {
-        for (int i = lane; i < a.pt_ld; i += 64) s_pt[hs][i] = a.page_table[b * a.pt_ld + i];
+        for (int i = lane; i < a.pt_ld; i += 64) s_pt[hs][i] = a.page_table[seq * a.pt_ld + i];
         float rows[3];
         load_head_rows<T, 3>(a, b, h, lane, rows);
 #pragma unroll
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(64 * HPB * NWH) void attn_self_decode_kernel(AttnAr
     const typename C::Raw kn_r = C::pack(kf), vn_r = C::pack(vf);
     T* Kp = reinterpret_cast<T*>(a.Kpool);
     T* Vp = reinterpret_cast<T*>(a.Vpool);
-    if (valid && kw == 0 && lane < LPK) {     // append this step's key/value row to the page of position t_cur
+    if (single && valid && kw == 0 && lane < LPK) {     // append this step's key/value row to the page of position t_cur
         const int64_t off = (((int64_t)s_pt[hs][t_cur / PS] * a.H + h) * PS + t_cur % PS) * HEAD_DIM + sub * EPL;
         *reinterpret_cast<typename C::Raw*>(Kp + off) = kn_r;
         *reinterpret_cast<typename C::Raw*>(Vp + off) = vn_r;
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(64 * HPB * NWH) void attn_self_decode_kernel(AttnAr
             const int64_t off = (((int64_t)s_pt[hs][key / PS] * a.H + h) * PS + key % PS) * HEAD_DIM + sub * EPL;
             kr[u] = __builtin_nontemporal_load(reinterpret_cast<const typename C::Raw*>(Kp + off));
             vr[u] = __builtin_nontemporal_load(reinterpret_cast<const typename C::Raw*>(Vp + off));
-            if (key == t_cur) { kr[u] = kn_r; vr[u] = vn_r; }
+            if (single && key == t_cur) { kr[u] = kn_r; vr[u] = vn_r; }
         }
         float s[U];
         float mt = -INFINITY;
@@ -471,11 +475,40 @@ static int check_common(const AttnArgs& a) {
     return 0;
 }
 
+// Prompt pass: the k/v rows of all a.B rows (q_group consecutive positions of each sequence), assembled from the q|k|v
+// projection's split-K tiles exactly as attn_self_decode_kernel assembles them, written to the paged cache.  One wave per
+// (row, head), 128-B stores.
+template <typename T>
+__global__ __launch_bounds__(256) void kv_append_kernel(AttnArgs a) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int rh = blockIdx.x * 4 + wid;
+    if (rh >= a.B * a.H) return;
+    const int r = rh / a.H, h = rh % a.H;
+    const int seq = r / a.q_group, t = *a.d_pos + r % a.q_group, PS = a.page_size;
+    float rows[3];
+    load_head_rows<T, 3>(a, r, h, lane, rows);
+    const int page = a.page_table[seq * a.pt_ld + t / PS];
+    const int64_t off = (((int64_t)page * a.H + h) * PS + t % PS) * HEAD_DIM + lane;
+    reinterpret_cast<T*>(a.Kpool)[off] = (T)rows[1];
+    reinterpret_cast<T*>(a.Vpool)[off] = (T)rows[2];
+}
+
+int launch_kv_append(const AttnArgs& a, hipStream_t st) {
+    if (check_common(a)) return -1;
+    if (!a.page_table || !a.d_pos || !a.Kpool || !a.Vpool || a.q_group < 1 || a.B % a.q_group || a.page_size != KV_PAGE) return -1;
+    if (!a.q_partial && (!a.Q || !a.Knew || !a.Vnew)) return -1;
+    dim3 grid((a.B * a.H + 3) / 4);
+    if (a.dt == DT_BF16) hipLaunchKernelGGL(kv_append_kernel<bf16>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(kv_append_kernel<float>, grid, dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int launch_attn_decode(const AttnArgs& a, hipStream_t st) {
     if (check_common(a)) return -1;
     if (a.n_q != 1 || a.n_split < 1) return -1;
     const bool paged = a.page_table != nullptr;
     if (paged) {
+        if (a.q_group < 1 || a.B % a.q_group || (a.q_group > 1 && a.page_size != KV_PAGE)) return -1;
         if (!a.d_pos || !a.Kpool || !a.Vpool || a.pt_ld > 448 || (a.page_size != 1 && a.page_size != KV_PAGE) || a.n_split != 1 || (!a.q_partial && (!a.Knew || !a.Vnew))) return -1;
         // 2 waves per head x 4 heads per workgroup measured best over {1,2,4} x {1,2,4,8} (tools/microbench): fewer, fatter
         // workgroups lose at long histories, more workgroups pay ~5 ns of dispatch each at short ones

@@ -81,8 +81,9 @@ int launch_reduce_layernorm(float* x, const float* partial, int n_split, const f
 // out[r][:] = bf16(gelu(bias + sum_s partial[s][r][:])): consumer side of a split-K decode GEMM with a GELU epilogue
 int launch_reduce_bias_gelu(const float* partial, int n_split, const float* bias, void* out_bf16, int rows, int N, hipStream_t st);
 // x[b][:] = tok_emb[tokens[b*ld_tok + *d_pos]][:] + pos_emb[*d_pos][:]   (fp32 out; embedding tables in `dt`)
+// group > 1 (prompt pass): row r embeds position *d_pos + r % group of sequence r / group (rows = sequences x group)
 int launch_embed(const void* tok_emb, const void* pos_emb, int dt, const int32_t* tokens, int ld_tok,
-                 const int32_t* d_pos, float* x, int B, int d, hipStream_t st);
+                 const int32_t* d_pos, float* x, int B, int d, hipStream_t st, int group = 1);
 int launch_convert_f32(const float* in, void* out, int out_dtype, int64_t n, hipStream_t st);
 int launch_to_f32(const void* in, int in_dtype, float* out, int64_t n, hipStream_t st);
 // mel (w, m, t) -> conv input xpad[w][1 + t][c_pad] (dtype dt); zero rows 0 and T+1, zero channels >= n_mels,
@@ -131,6 +132,9 @@ struct AttnArgs {
     void* Kpool = nullptr; void* Vpool = nullptr;   // written at position *d_pos with the new token's k/v
     const void* Knew = nullptr; const void* Vnew = nullptr; int64_t new_sb = 0;  // k/v of the current token: + b*new_sb + h*64
     const int32_t* d_pos = nullptr;      // device scalar: current position t (keys 0..t are attended)
+    // prompt pass (paged self-attention only): q_group consecutive rows are consecutive positions *d_pos + r % q_group of
+    // ONE sequence r / q_group (its page-table row, its cache); their k/v rows are appended by launch_kv_append first
+    int q_group = 1;
     // output o(b, iq, h) at O + b*o_sb + iq*o_sq + h*o_sh
     void* O = nullptr; int64_t o_sb = 0, o_sq = 0, o_sh = HEAD_DIM;
     int B = 0, H = 0;
@@ -138,6 +142,7 @@ struct AttnArgs {
     float* partial = nullptr; int n_split = 1;
 };
 int launch_attn_decode(const AttnArgs& a, hipStream_t st);     // n_q == 1, waves split the keys
+int launch_kv_append(const AttnArgs& a, hipStream_t st);       // prompt pass: write the k/v rows of a.B rows into the paged cache
 int launch_attn_rows(const AttnArgs& a, hipStream_t st);       // many queries, non-causal, dense K/V (fp32 encoder path)
 int launch_attn_flash_bf16(const AttnArgs& a, hipStream_t st); // MFMA flash attention, dense bf16 K/V, non-causal
 
@@ -157,6 +162,8 @@ struct SamplerArgs {
     int tok_eot = 0, tok_blank = 0, tok_no_speech = 0, tok_no_timestamps = 0, tok_timestamp_begin = 0;
     int without_timestamps = 1, suppress_blank = 1, max_initial_ts = 50;
     int forced = 0;                                // 1: teacher forcing, tokens are never written
+    int group = 1;                                 // prompt pass: B rows = sequences x group positions; row r is position
+                                                   // *d_pos + r % group of sequence r / group; the position advances by group
     float temperature = 0.f;                       // > 0: sample from softmax(logits / T) (Gumbel-max, counter-based RNG)
     uint32_t seed = 0;
     // when set, {temperature bits, seed, sample_len} are read from device memory instead, so a captured decode-step graph

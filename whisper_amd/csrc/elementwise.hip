@@ -198,18 +198,19 @@ int launch_reduce_bias_gelu(const float* partial, int n_split, const float* bias
 // ---------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void embed_kernel(const T* __restrict__ tok_emb, const T* __restrict__ pos_emb, const int32_t* __restrict__ tokens,
-                             int ld_tok, const int32_t* __restrict__ d_pos, float* __restrict__ x, int d) {
-    const int b = blockIdx.x, t = *d_pos;
+                             int ld_tok, const int32_t* __restrict__ d_pos, float* __restrict__ x, int d, int group) {
+    const int r = blockIdx.x, b = r / group, t = *d_pos + r % group;
     const int token = tokens[b * ld_tok + t];
     const T* te = tok_emb + (int64_t)token * d;
     const T* pe = pos_emb + (int64_t)t * d;
-    for (int i = threadIdx.x; i < d; i += blockDim.x) x[(int64_t)b * d + i] = (float)te[i] + (float)pe[i];
+    for (int i = threadIdx.x; i < d; i += blockDim.x) x[(int64_t)r * d + i] = (float)te[i] + (float)pe[i];
 }
 
 int launch_embed(const void* tok_emb, const void* pos_emb, int dt, const int32_t* tokens, int ld_tok, const int32_t* d_pos,
-                 float* x, int B, int d, hipStream_t st) {
-    if (dt == DT_F32) hipLaunchKernelGGL(embed_kernel<float>, dim3(B), dim3(256), 0, st, (const float*)tok_emb, (const float*)pos_emb, tokens, ld_tok, d_pos, x, d);
-    else hipLaunchKernelGGL(embed_kernel<bf16>, dim3(B), dim3(256), 0, st, (const bf16*)tok_emb, (const bf16*)pos_emb, tokens, ld_tok, d_pos, x, d);
+                 float* x, int B, int d, hipStream_t st, int group) {
+    if (group < 1) return -1;
+    if (dt == DT_F32) hipLaunchKernelGGL(embed_kernel<float>, dim3(B), dim3(256), 0, st, (const float*)tok_emb, (const float*)pos_emb, tokens, ld_tok, d_pos, x, d, group);
+    else hipLaunchKernelGGL(embed_kernel<bf16>, dim3(B), dim3(256), 0, st, (const bf16*)tok_emb, (const bf16*)pos_emb, tokens, ld_tok, d_pos, x, d, group);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -360,9 +361,10 @@ __global__ __launch_bounds__(SAMP_NT) void sampler_kernel(SamplerArgs s) {
     __shared__ MS sh_msa[SAMP_NW], sh_mst[SAMP_NW];
     __shared__ float sh_f[SAMP_NW], sh_g[SAMP_NW];
     __shared__ int sh_flags[8];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int t = *s.d_pos;
-    const float* lg = s.logits + (int64_t)b * s.ldl;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int t0 = *s.d_pos;
+    const int b = blockIdx.x / s.group, t = t0 + blockIdx.x % s.group;     // group > 1: forced prompt pass, one row per position
+    const float* lg = s.logits + (int64_t)blockIdx.x * s.ldl;
     const int V = s.n_vocab;
     const int n_prompt = s.row_n_prompt ? s.row_n_prompt[b] : s.n_prompt;
     const int sot_index = s.row_sot ? s.row_sot[b] : s.sot_index;
@@ -488,12 +490,13 @@ __global__ __launch_bounds__(SAMP_NT) void sampler_kernel(SamplerArgs s) {
     __syncthreads();
     if (tid == 0) {
         const int ticket = atomicAdd(s.d_block_counter, 1);
-        if (ticket == s.B - 1) { *s.d_block_counter = 0; *s.d_pos = t + 1; }
+        if (ticket == s.B - 1) { *s.d_block_counter = 0; *s.d_pos = t0 + s.group; }
     }
 }
 
 int launch_sampler(const SamplerArgs& s, hipStream_t st) {
     if (s.B <= 0 || !s.logits || !s.tokens || !s.d_pos || !s.d_block_counter || !s.suppress) return -1;
+    if (s.group < 1 || (s.group > 1 && (!s.forced || s.B % s.group))) return -1;
     hipLaunchKernelGGL(sampler_kernel, dim3(s.B), dim3(SAMP_NT), 0, st, s);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

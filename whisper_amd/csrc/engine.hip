@@ -704,7 +704,11 @@ static int decode_step_f32(wx_engine* e, int B, const SamplerArgs* sa, hipStream
 // the cross-attention query projection split K over workgroups and hand raw fp32 partial tiles to their consumer -- the
 // next LayerNorm (reduce + bias + residual + LN in one kernel) or the attention kernel's q/k/v load -- so every weight
 // byte streams once with the whole chip pulling, and no launch is added.  11 launches per layer.
-static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, float* apartial, bool prof_ok, hipStream_t st) {
+// G > 1 = prompt pass: the B rows are G consecutive forced positions (*d_pos ...) of B / G sequences, row r = sequence r / G,
+// position r % G.  Row-wise kernels do not care; self-attention appends all new k/v rows first and then reads the cache
+// causally per row, cross-attention shares a window's K/V stream among its G rows (the beam-search grouping).
+static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, float* apartial, bool prof_ok, hipStream_t st,
+                              int G = 1, bool want_logits = true) {
     const int d = e->d, dtp = e->dt, T = e->T;
     const size_t es = dtype_size(dtp);
     const wx_config& c = e->cfg;
@@ -712,7 +716,8 @@ static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, floa
     char* dxn = (char*)e->dxn + (size_t)b0 * d * es;
     char* datt = (char*)e->datt + (size_t)b0 * d * es;
     char* dhid = (char*)e->dhid + (size_t)b0 * 4 * d * es;
-    WX_TRY(launch_embed(e->tok_emb, e->dec_pos, dtp, e->tokens + (size_t)b0 * c.n_text_ctx, c.n_text_ctx, e->d_pos, dx, B, d, st));
+    if (G < 1 || B % G || (G > 1 && (e->beam_n > 0 || b0 != 0))) return fail(WX_ERR_INVALID, "bad prompt-pass grouping");
+    WX_TRY(launch_embed(e->tok_emb, e->dec_pos, dtp, e->tokens + (size_t)b0 * c.n_text_ctx, c.n_text_ctx, e->d_pos, dx, B, d, st, G));
     const size_t cross_layer = (size_t)c.max_batch * e->Ht * T * HEAD_DIM, cross_b0 = (size_t)b0 * e->Ht * T * HEAD_DIM;
     const size_t self_layer = (size_t)c.max_batch * e->n_pages_seq * e->Ht * KV_PAGE * HEAD_DIM;
     const int n_split = cross_attn_key_split(e);
@@ -742,7 +747,8 @@ static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, floa
             a.dt = dtp; a.q_partial = gpartial; a.q_bias = L.self.bqkv; a.q_nsplit = s_qkv; a.q_scale = e->qk_scale; a.q_sb = 3 * d; a.n_q = 1;
             set_self_cache(e, a, b0);
             a.Kpool = (char*)e->selfK + self_layer * i * es; a.Vpool = (char*)e->selfV + self_layer * i * es;
-            a.d_pos = e->d_pos; a.O = datt; a.o_sb = d; a.B = B; a.H = e->Ht; a.n_split = 1;
+            a.d_pos = e->d_pos; a.O = datt; a.o_sb = d; a.B = B; a.H = e->Ht; a.n_split = 1; a.q_group = G;
+            if (G > 1) WX_TRY(launch_kv_append(a, st));
             WX_TRY(launch_attn_decode(a, st));
         }
         WX_TRY(split_gemm(datt, d, L.self.wo, d, s_dd));
@@ -752,7 +758,7 @@ static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, floa
             AttnArgs a;
             a.dt = dtp; a.q_partial = gpartial; a.q_bias = L.xbq; a.q_nsplit = s_dd; a.q_scale = e->qk_scale; a.q_sb = d; a.n_q = 1;
             a.K = (char*)e->crossK + (cross_layer * i + cross_b0) * es; a.V = (char*)e->crossV + (cross_layer * i + cross_b0) * es;
-            a.kv_sbh = (int64_t)T * HEAD_DIM; a.n_keys = T; a.kv_group = e->beam_n > 0 ? e->beam_n : 1;
+            a.kv_sbh = (int64_t)T * HEAD_DIM; a.n_keys = T; a.kv_group = e->beam_n > 0 ? e->beam_n : G;
             a.O = datt; a.o_sb = d; a.B = B; a.H = e->Ht; a.n_split = n_split; a.partial = apartial;
             const bool prof = prof_ok && e->prof_on && e->prof_used + 2 <= e->prof_events.size();
             if (prof) HIP_TRY(hipEventRecord(e->prof_events[e->prof_used], st));
@@ -771,6 +777,7 @@ static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, floa
         WX_TRY(split_gemm(dhid, 4 * d, L.w2, 4 * d, s_fc2));
         pend_split = s_fc2; pend_bias = L.b2;
     }
+    if (!want_logits) return 0;      // prompt pass with no row at its SOT position: the residual stream is not needed again
     WX_TRY(launch_reduce_layernorm(dx, gpartial, pend_split, pend_bias, e->declnf_g, e->declnf_b, dxn, dtp, B, d, st));
     {
         GemmArgs g = gemm_basic(e, dxn, d, e->tok_emb, B, e->vocab_pad, d);
@@ -884,7 +891,32 @@ static int decode_rows_impl(wx_engine* e, int32_t B, const int32_t* h_rows, cons
         for (auto& ev : e->prof_events) HIP_TRY(hipEventCreate(&ev));
     }
     e->prof_used = 0; e->prof_ms = 0.0; e->prof_launches = 0;
-    for (int s = 0; s < total_steps; ++s) {
+    // Prompt pass (bf16 split-K path): positions 0 .. min_np - 2 are forced for every row and sample nothing, so they are
+    // fed G at a time as rows = sequences x G positions (G <= 8, rows <= min(80, max_batch)) instead of one step each:
+    // a 224-id previous-text prompt of one file takes 28 passes, not 224 steps.  Row-wise arithmetic is unchanged, so ids
+    // and log-probabilities are bit-identical to stepwise feeding (tests/test_gpu_parity.py); WX_NO_PREFILL=1 disables it.
+    int s_begin = 0;
+    {
+        const char* np_env = getenv("WX_NO_PREFILL");
+        const int row_cap = c.max_batch < DG_MAX_ROWS ? c.max_batch : DG_MAX_ROWS;
+        int G = row_cap / B; if (G > 8) G = 8;
+        if (e->dt == DT_BF16 && G >= 2 && !(np_env && np_env[0] == '1')) {
+            SamplerArgs pa = make_sampler(e, B, o, 1);
+            pa.row_sot = e->row_sot;                   // the no-speech probability is read at each row's own SOT position
+            while (min_np - 1 - s_begin >= 2) {
+                const int g = (min_np - 1 - s_begin) < G ? (min_np - 1 - s_begin) : G;
+                bool sot_here = false;
+                for (int b = 0; b < B; ++b) if (h_sot[b] >= s_begin && h_sot[b] < s_begin + g) sot_here = true;
+                int r = decode_layers_bf16(e, 0, B * g, e->gpartial, e->partial, false, st, g, sot_here);
+                if (r) return r;
+                pa.B = B * g; pa.group = g;
+                pa.no_speech = sot_here ? e->no_speech : nullptr;
+                WX_TRY(launch_sampler(pa, st));        // forced: only the no-speech read and the position += g
+                s_begin += g;
+            }
+        }
+    }
+    for (int s = s_begin; s < total_steps; ++s) {
         e->prof_on = want_prof && s >= min_np - 1 && ((s - (min_np - 1)) % o.profile_stride == 0);
         if (exec) HIP_TRY(hipGraphLaunch(exec, st));
         else { int r = decode_step(e, B, &sa, st); e->prof_on = false; if (r) return r; }
