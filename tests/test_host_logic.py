@@ -142,7 +142,10 @@ def test_dropin_result_shaping(monkeypatch, tmp_path):
     sr = _fresh_dropin(monkeypatch)
     calls = []
 
-    def fake_transcribe(path, language=None, prompt=None):
+    seen = {}
+
+    def fake_transcribe(path, language=None, prompt=None, mode="windows", **kw):
+        seen["mode"] = mode
         calls.append((path, language))
         return {"text": "  тестовый текст ", "confidence": 0.95, "chunks_processed": 1, "language": "ru"}
 
@@ -150,6 +153,7 @@ def test_dropin_result_shaping(monkeypatch, tmp_path):
     monkeypatch.setattr(sr._tx, "transcribe", fake_transcribe)
     out = asyncio.run(sr.transcribe_audio(tmp_path / "a.wav", detailed=True))
     assert out == ("тестовый текст", 0.95, "ru") and isinstance(out[1], float)
+    assert seen["mode"] == "windows"                                                  # default decode_mode
     out = asyncio.run(sr.transcribe_audio(tmp_path / "a.wav", detailed=False))       # privacy branch still runs the model
     assert out == ("Voice authentication required for full transcription", 0.5, "ru") and len(calls) == 2
 

@@ -11,7 +11,8 @@ Install: ``sys.modules["app.transcription.speech_recognitio
 before ``app.transcription.openai_whisper`` is imported (it binds ``transcribe_audio`` at import, ref:openai_whisper.py:14).
 Build-specific settings live in a NEW config section so existing keys keep their meaning:
     whisper_amd: {checkpoint: /path/model.pt, vocab: /path/multilingual.tiktoken, precision: bf16, max_batch: 16,
-                  allow_synthetic_weights: false, confidence_mode: reference}
+                  allow_synthetic_weights: false, confidence_mode: reference,
+                  decode_mode: windows | sequential, beam_size: null}
 """
 from __future__ import annotations
 
@@ -92,7 +93,13 @@ async def transcribe_audio(audio_path: Path, detailed: bool = True) -> Tuple[str
     if whisper_model is None:
         raise RuntimeError("Whisper model not initialized")
     try:
-        result = _tx.transcribe(str(audio_path), language=LANGUAGE)
+        # decode_mode "windows" (default): independent 30 s windows, batched and sharded; "sequential": upstream's own
+        # long-form loop with upstream's defaults (timestamps, previous-text prompt, temperature fallback) -- what the
+        # reference's call really runs (ref:speech_recognition.py:48-52 passes only language, task, fp16)
+        kw = {}
+        if _AMD.get("beam_size"):
+            kw["beam_size"] = int(_AMD["beam_size"])
+        result = _tx.transcribe(str(audio_path), language=LANGUAGE, mode=str(_AMD.get("decode_mode", "windows")), **kw)
         text = result["text"].strip()
         language = result.get("language", "unknown")
         confidence = float(result.get("confidence", 0.0))
