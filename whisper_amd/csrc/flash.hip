@@ -24,7 +24,10 @@ constexpr int FA_VROW = 160;              // V image row bytes (128 data + 32 pa
 constexpr int FA_KBYTES = FA_KT * FA_KROW, FA_VBYTES = FA_KT * FA_VROW;
 constexpr float FA_LOG2E = 1.4426950408889634f;
 
-__global__ __launch_bounds__(256) void attn_flash_bf16_kernel(AttnArgs a) {
+// launch_bounds(256, 3): three waves per SIMD (158 VGPRs, no spills).  The softmax is VALU work (~200 instructions per lane
+// per 64-key tile) that can only overlap the MFMAs of ANOTHER wave: at the compiler's default allocation (204 registers, two
+// waves per SIMD) a launch took 1439 us, at three 1082 us; four needs 128 registers, spills, and takes 3518 us.
+__global__ __launch_bounds__(256, 3) void attn_flash_bf16_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[2 * (FA_KBYTES + FA_VBYTES)];
     // 1-D grid, XCD-aware: blocks that share an XCD (blockIdx % 8) take ALL query blocks of one (batch, head) before the
     // next, so a head's K/V (384 KB) is fetched into one L2 instead of all eight (measured: 4.2 GB -> of L2 misses per launch).
