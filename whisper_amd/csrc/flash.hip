@@ -142,8 +142,12 @@ __global__ __launch_bounds__(256, 3) void attn_flash_bf16_kernel(AttnArgs a) {
                 }
             l_run[qt] = l_run[qt] * alpha + ls;
             m_run[qt] = mn;
+            // after the first few tiles the running maximum rarely moves: alpha is exactly 1 on every lane and the 16
+            // multiplies (of ~100 VALU instructions per tile and query tile) are skipped -- bit-identical either way
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) acc_o[dt][qt] *= alpha;
+                for (int dt = 0; dt < 4; ++dt) acc_o[dt][qt] *= alpha;
+            }
             // k-slot order of the P^T operand = key order of the S^T accumulators: step s takes tiles 2s and 2s+1
 #pragma unroll
             for (int s = 0; s < 2; ++s)
