@@ -135,7 +135,7 @@ def main():
         mark()
         if args.beam:
             rb = eng.decode_beam(B, prompt, beam_size=args.beam, max_new_tokens=args.max_new_tokens, use_graph=use_graph)
-            toks = torch.full((B, dims.n_text_ctx), eng.tok.eot, dtype=torch.int32)
+            toks = torch.full((B, dims.n_text_ctx + 1), eng.tok.eot, dtype=torch.int32)
             for b, t in enumerate(rb["tokens"]):
                 toks[b, :len(t)] = torch.tensor(t, dtype=torch.int32)
             r = {"tokens": toks.to(dev), "n_tokens": torch.tensor([len(t) for t in rb["tokens"]], dtype=torch.int32, device=dev),

@@ -115,9 +115,11 @@ int wx_encode(wx_engine* e, const float* d_mel, int64_t win_stride, int64_t row_
 int wx_get_encoder_output(wx_engine* e, int32_t B, float* d_out, void* stream);
 
 /* replaces DecodingTask.run greedy (temperature 0) for the B windows of the last wx_encode.
- * h_prompt: n_prompt ids shared by all windows.  Outputs (device): d_tokens [B][n_text_ctx] int32 (prompt +
+ * h_prompt: n_prompt ids shared by all windows.  Outputs (device): d_tokens [B][n_text_ctx + 1] int32 (prompt +
  * sampled ids, EOT-padded after the end), d_n_tokens [B] (count of sampled ids before EOT), d_sum_logprob [B],
- * d_no_speech_prob [B].  *h_steps (optional) receives the number of sampling steps executed. */
+ * d_no_speech_prob [B].  *h_steps (optional) receives the number of sampling steps executed.  Token rows hold
+ * n_text_ctx + 1 ids because upstream's loop still samples from the last position (it stops once a row is LONGER than
+ * n_text_ctx). */
 int wx_decode_greedy(wx_engine* e, int32_t B, const int32_t* h_prompt, const wx_decode_opts* opts,
                      int32_t* d_tokens, int32_t* d_n_tokens, float* d_sum_logprob, float* d_no_speech_prob,
                      int32_t* h_steps, void* stream);
@@ -125,7 +127,7 @@ int wx_decode_greedy(wx_engine* e, int32_t B, const int32_t* h_prompt, const wx_
 /* wx_decode_greedy with a prompt PER WINDOW and an optional temperature: what upstream's sequential long-form loop needs
  * (Whisper.transcribe inside ref:speech_recognition.py:55: every window is conditioned on the text decoded before it,
  * "condition_on_previous_text", and re-decoded at temperatures 0.2 ... 1.0 when the compression-ratio / log-probability
- * checks fail, "decode_with_fallback").  h_prompts [B][n_text_ctx] holds each row's initial ids (h_n_prompt[b] of them,
+ * checks fail, "decode_with_fallback").  h_prompts [B][n_text_ctx + 1] holds each row's initial ids (h_n_prompt[b] of them,
  * <|startoftranscript|> at h_sot_index[b]); opts->n_prompt / sot_index are ignored.  Rows run in lockstep over positions,
  * each starts sampling after its own prompt and stops at EOT, after max_new_tokens ids or at n_text_ctx.  temperature > 0
  * samples from softmax(logits / T) with a counter-based generator seeded by `seed` (upstream draws from torch's global
@@ -142,8 +144,8 @@ int wx_decode_rows(wx_engine* e, int32_t B, const int32_t* h_prompts, const int3
  * list while it holds fewer than max_candidates = round(beam_size * patience) entries, the first beam_size others kept as
  * beams; decoding stops when every window's list is full (or at sample_len).  The self-attention cache follows the
  * beams through index rows (no K/V copy); the beams of a window share one pass over its cross-attention K/V.
- * Outputs (device): d_fin_tokens [B][max_candidates][n_text_ctx] (prompt + ids + EOT padding, in finished order),
- * d_fin_sum_logprob [B][max_candidates], d_fin_count [B], and the live beams d_beam_tokens [B*beam_size][n_text_ctx],
+ * Outputs (device): d_fin_tokens [B][max_candidates][n_text_ctx + 1] (prompt + ids + EOT padding, in finished order),
+ * d_fin_sum_logprob [B][max_candidates], d_fin_count [B], and the live beams d_beam_tokens [B*beam_size][n_text_ctx + 1],
  * d_beam_sum_logprob [B*beam_size] -- upstream finalize() (top up short lists from the beams) and the
  * sum_logprob / length ranking are a few dozen host operations and are left to the caller (whisper_amd/engine.py). */
 int wx_decode_beam(wx_engine* e, int32_t B, int32_t beam_size, float patience, const int32_t* h_prompt,

@@ -236,31 +236,10 @@ def test_long_prompt_fills_the_text_context_fp32(models):
     r = eng.decode_greedy(2, init)
     n = r["n_tokens"].cpu().tolist()
     t = r["tokens"].cpu()
-    room = dims.n_text_ctx - len(init)
     for b in range(2):
-        # Known one-id divergence at the context limit (DESIGN.md "Divergences"): upstream's loop stops once the row holds
-        # n_text_ctx + 1 ids (it still samples from position n_text_ctx - 1); the engine's rows hold n_text_ctx ids.
-        assert len(ref["tokens"][b]) <= room + 1
-        assert t[b, len(init):len(init) + n[b]].tolist() == ref["tokens"][b][:room]
-        assert n[b] == min(len(ref["tokens"][b]), room)
-
-
-def test_bf16_greedy_agrees_with_oracle_where_margin_is_large(models):
-    dims, sd, eng = models("tiny", "bf16")
-    om = wo.OracleWhisper(dims, sd)
-    tok = eng.tok
-    mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(s), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000] for s in range(2)])
-    init = wo.initial_tokens(tok, 0)
-    with torch.no_grad():
-        ref = wo.greedy_decode(om, om.encode(mels), init, tok, wo.suppress_token_ids(tok, ck.non_speech_suppress_ids()), max_new_tokens=16)
-    eng.encode_windows(mels)
-    r = eng.decode_greedy(2, init, max_new_tokens=16)
-    t = r["tokens"].cpu()
-    for b in range(2):
-        for i, want in enumerate(ref["tokens"][b]):
-            if ref["margins"][i, b] < 0.15:      # bf16 logits move by O(1e-2): stop comparing at the first close call
-                break
-            assert int(t[b, len(init) + i]) == want
+        # upstream's loop stops once the row holds n_text_ctx + 1 ids: it still samples from position n_text_ctx - 1
+        assert len(ref["tokens"][b]) == dims.n_text_ctx + 1 - len(init)       # eot_boost 0: no EOT before the limit
+        assert t[b, len(init):len(init) + n[b]].tolist() == ref["tokens"][b]
 
 
 @pytest.mark.parametrize("precision,rows", [("fp32", 96), ("bf16", 72), ("bf16", 80), ("bf16", 96)])
@@ -320,6 +299,24 @@ def test_beam_search_matches_oracle_fp32(models, name, beam, boost, use_graph):
         g = wo.greedy_decode(om, om.encode(mels), init, tok, wo.suppress_token_ids(tok, ck.non_speech_suppress_ids()), max_new_tokens=8)
     t, n = r["tokens"].cpu(), r["n_tokens"].cpu()
     assert [t[b, len(init):len(init) + int(n[b])].tolist() for b in range(3)] == g["tokens"]
+
+
+def test_beam_search_at_the_text_context_limit_fp32(models):
+    """Beam search from a maximum-length previous-text prompt with no EOT in sight: like upstream, the beams take their last
+    step from position n_text_ctx - 1 and end with n_text_ctx + 1 ids; finalize() then ranks the live beams."""
+    dims, sd, eng = models("micro", "fp32", max_batch=4, eot_boost=0.0)
+    om = wo.OracleWhisper(dims, sd)
+    tok = eng.tok
+    rng = np.random.default_rng(6)
+    init = eng.initial_tokens(0, prompt_ids=[int(x) for x in rng.integers(0, tok.eot, size=230)])
+    mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(70 + s), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000] for s in range(2)])
+    with torch.no_grad():
+        ref = wo.beam_search_decode(om, om.encode(mels), init, tok, wo.suppress_token_ids(tok, ck.non_speech_suppress_ids()), beam_size=2)
+    eng.encode_windows(mels)
+    got = eng.decode_beam(2, init, beam_size=2)
+    assert got["steps"] == ref["steps"] == dims.n_text_ctx + 1 - len(init)
+    assert got["tokens"] == ref["tokens"] and all(len(t) == dims.n_text_ctx + 1 - len(init) for t in got["tokens"])
+    np.testing.assert_allclose(got["sum_logprobs"], ref["sum_logprobs"], rtol=1e-4, atol=5e-3)
 
 
 def test_beam_search_bf16_shares_cross_kv(models):

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void beam_gather_kernel(BeamArgs s) {
     const int from = s.src[r];
     for (int i = threadIdx.x; i <= t; i += 256) {
         s.tokens_tmp[(int64_t)r * s.ld_tok + i] = s.tokens[(int64_t)from * s.ld_tok + i];
-        s.node_tmp[(int64_t)r * s.ld_tok + i] = s.node[(int64_t)from * s.ld_tok + i];
+        s.node_tmp[(int64_t)r * s.ld_node + i] = s.node[(int64_t)from * s.ld_node + i];
     }
 }
 
@@ -262,13 +262,11 @@ __global__ __launch_bounds__(256) void beam_commit_kernel(BeamArgs s) {
     const int r = blockIdx.x, t = *s.d_pos, R = gridDim.x;
     for (int i = threadIdx.x; i <= t; i += 256) {
         s.tokens[(int64_t)r * s.ld_tok + i] = s.tokens_tmp[(int64_t)r * s.ld_tok + i];
-        s.node[(int64_t)r * s.ld_tok + i] = s.node_tmp[(int64_t)r * s.ld_tok + i];
+        s.node[(int64_t)r * s.ld_node + i] = s.node_tmp[(int64_t)r * s.ld_node + i];
     }
     if (threadIdx.x == 0) {
-        if (t + 1 < s.ld_tok) {
-            s.tokens[(int64_t)r * s.ld_tok + t + 1] = s.next_tok[r];
-            s.node[(int64_t)r * s.ld_tok + t + 1] = (t + 1) * R + r;  // a fresh KV node for the next position
-        }
+        if (t + 1 < s.ld_tok) s.tokens[(int64_t)r * s.ld_tok + t + 1] = s.next_tok[r];
+        if (t + 1 < s.ld_node) s.node[(int64_t)r * s.ld_node + t + 1] = (t + 1) * R + r;  // a fresh KV node for the next position
         s.sum_logprob[r] = s.sum_tmp[r];
     }
     __syncthreads();
@@ -281,6 +279,7 @@ __global__ __launch_bounds__(256) void beam_commit_kernel(BeamArgs s) {
 
 int launch_beam_step(const BeamArgs& s, hipStream_t st) {
     if (s.B <= 0 || s.n < 1 || s.n > 8 || s.max_candidates < s.n || !s.logits || !s.tokens || !s.d_pos) return -1;
+    if (s.ld_node <= 0 || s.ld_tok < s.ld_node) return -1;
     const int R = s.B * s.n;
     if (s.n + 1 <= 6) hipLaunchKernelGGL(beam_topk_kernel<6>, dim3(R), dim3(BT_NT), 0, st, s);
     else hipLaunchKernelGGL(beam_topk_kernel<BEAM_MAXK>, dim3(R), dim3(BT_NT), 0, st, s);

@@ -149,7 +149,7 @@ int launch_attn_flash_bf16(const AttnArgs& a, hipStream_t st); // MFMA flash att
 // ---- sampler ------------------------------------------------------------------------------------------
 struct SamplerArgs {
     const float* logits = nullptr; int64_t ldl = 0; int n_vocab = 0;
-    int32_t* tokens = nullptr; int ld_tok = 0;     // [B][n_text_ctx]
+    int32_t* tokens = nullptr; int ld_tok = 0;     // [B][n_text_ctx + 1]
     int32_t* d_pos = nullptr;                      // incremented by the last block
     int32_t* d_block_counter = nullptr;            // zero-initialised scratch counter
     const uint8_t* suppress = nullptr;             // [n_vocab] 1 = masked
@@ -178,8 +178,8 @@ int launch_finish_tokens(int32_t* tokens, int ld_tok, int n_prompt, const int32_
 // ---- beam search ----------------------------------------------------------------------------------------
 struct BeamArgs {
     const float* logits = nullptr; int64_t ldl = 0; int n_vocab = 0;
-    int32_t* tokens = nullptr; int32_t* tokens_tmp = nullptr; int ld_tok = 0;   // [R][n_text_ctx]
-    int32_t* node = nullptr; int32_t* node_tmp = nullptr;                       // [R][n_text_ctx] KV node of every position
+    int32_t* tokens = nullptr; int32_t* tokens_tmp = nullptr; int ld_tok = 0;   // [R][n_text_ctx + 1]
+    int32_t* node = nullptr; int32_t* node_tmp = nullptr; int ld_node = 0;      // [R][n_text_ctx] KV node of every position
     float* sum_logprob = nullptr; float* sum_tmp = nullptr;                     // [R]
     float* cand_score = nullptr; int32_t* cand_tok = nullptr;                   // [R][9] proposals, best first
     int32_t* src = nullptr; int32_t* next_tok = nullptr;                        // [R]

@@ -58,6 +58,7 @@ struct wx_engine {
 
     // dims
     int d = 0, H = 0, dt_ = 0, Ht = 0, c_pad = 0, vocab_pad = 0, T = 0, n_pages_seq = 0;
+    int ld_tok = 0;     // ids per token row = n_text_ctx + 1: upstream's loop still samples from position n_text_ctx - 1
     float qk_scale = 1.f;
 
     // weights
@@ -245,6 +246,7 @@ int wx_create(const wx_config* cfg, wx_engine** out) {
     e->vocab_pad = (c.n_vocab + 15) / 16 * 16;
     e->T = c.n_audio_ctx;
     e->n_pages_seq = c.n_text_ctx / KV_PAGE;
+    e->ld_tok = c.n_text_ctx + 1;
     e->qk_scale = powf((float)HEAD_DIM, -0.25f);
     hipError_t r = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
     if (r == hipSuccess) r = hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming);
@@ -432,7 +434,7 @@ int wx_finalize(wx_engine* e) {
     if ((r = A(&e->dhid, (size_t)B * 4 * d * es))) return r;
     if ((r = A(&e->dq, (size_t)B * d * es))) return r;
     if ((r = A((void**)&e->logits, (size_t)B * e->vocab_pad * 4))) return r;
-    if ((r = A((void**)&e->tokens, (size_t)B * c.n_text_ctx * 4))) return r;
+    if ((r = A((void**)&e->tokens, (size_t)B * e->ld_tok * 4))) return r;
     if ((r = A((void**)&e->d_pos, 64))) return r;
     e->d_counter = e->d_pos + 4; e->n_finished = e->d_pos + 8;
     HIP_TRY(hipMemset(e->d_pos, 0, 64));
@@ -445,8 +447,8 @@ int wx_finalize(wx_engine* e) {
     if ((r = A((void**)&e->partial, (size_t)B * e->Ht * 8 * (HEAD_DIM + 2) * 4))) return r;
     if ((r = A((void**)&e->gpartial, (size_t)16 * B * 3 * d * 4))) return r;   // split-K partial tiles of the decode GEMMs
     {   // beam search
-        const size_t ctx = c.n_text_ctx;
-        if ((r = A((void**)&e->b_tokens_tmp, (size_t)B * ctx * 4))) return r;
+        const size_t ctx = c.n_text_ctx, lt = e->ld_tok;
+        if ((r = A((void**)&e->b_tokens_tmp, (size_t)B * lt * 4))) return r;
         if ((r = A((void**)&e->b_node, (size_t)B * ctx * 4))) return r;
         if ((r = A((void**)&e->b_node_tmp, (size_t)B * ctx * 4))) return r;
         if ((r = A((void**)&e->b_cand_tok, (size_t)B * 9 * 4))) return r;
@@ -454,7 +456,7 @@ int wx_finalize(wx_engine* e) {
         if ((r = A((void**)&e->b_src, (size_t)B * 4))) return r;
         if ((r = A((void**)&e->b_next, (size_t)B * 4))) return r;
         if ((r = A((void**)&e->b_sum_tmp, (size_t)B * 4))) return r;
-        if ((r = A((void**)&e->b_fin_tokens, (size_t)2 * B * ctx * 4))) return r;
+        if ((r = A((void**)&e->b_fin_tokens, (size_t)2 * B * lt * 4))) return r;
         if ((r = A((void**)&e->b_fin_score, (size_t)2 * B * 4))) return r;
         if ((r = A((void**)&e->b_fin_count, (size_t)B * 4))) return r;
     }
@@ -628,7 +630,7 @@ static int decode_step_f32(wx_engine* e, int B, const SamplerArgs* sa, hipStream
     const int d = e->d, dtp = e->dt, T = e->T;
     const size_t es = dtype_size(dtp);
     const wx_config& c = e->cfg;
-    WX_TRY(launch_embed(e->tok_emb, e->dec_pos, dtp, e->tokens, c.n_text_ctx, e->d_pos, e->dx, B, d, st));
+    WX_TRY(launch_embed(e->tok_emb, e->dec_pos, dtp, e->tokens, e->ld_tok, e->d_pos, e->dx, B, d, st));
     const size_t cross_layer = (size_t)c.max_batch * e->Ht * T * HEAD_DIM;
     const size_t self_layer = (size_t)c.max_batch * e->n_pages_seq * e->Ht * KV_PAGE * HEAD_DIM;
     const int n_split = cross_attn_key_split(e);
@@ -717,7 +719,7 @@ static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, floa
     char* datt = (char*)e->datt + (size_t)b0 * d * es;
     char* dhid = (char*)e->dhid + (size_t)b0 * 4 * d * es;
     if (G < 1 || B % G || (G > 1 && (e->beam_n > 0 || b0 != 0))) return fail(WX_ERR_INVALID, "bad prompt-pass grouping");
-    WX_TRY(launch_embed(e->tok_emb, e->dec_pos, dtp, e->tokens + (size_t)b0 * c.n_text_ctx, c.n_text_ctx, e->d_pos, dx, B, d, st, G));
+    WX_TRY(launch_embed(e->tok_emb, e->dec_pos, dtp, e->tokens + (size_t)b0 * e->ld_tok, e->ld_tok, e->d_pos, dx, B, d, st, G));
     const size_t cross_layer = (size_t)c.max_batch * e->Ht * T * HEAD_DIM, cross_b0 = (size_t)b0 * e->Ht * T * HEAD_DIM;
     const size_t self_layer = (size_t)c.max_batch * e->n_pages_seq * e->Ht * KV_PAGE * HEAD_DIM;
     const int n_split = cross_attn_key_split(e);
@@ -803,7 +805,7 @@ static SamplerArgs make_sampler(wx_engine* e, int B, const wx_decode_opts& o, in
     const wx_config& c = e->cfg;
     SamplerArgs s;
     s.logits = e->logits; s.ldl = e->vocab_pad; s.n_vocab = c.n_vocab;
-    s.tokens = e->tokens; s.ld_tok = c.n_text_ctx; s.d_pos = e->d_pos; s.d_block_counter = e->d_counter;
+    s.tokens = e->tokens; s.ld_tok = e->ld_tok; s.d_pos = e->d_pos; s.d_block_counter = e->d_counter;
     s.suppress = e->suppress; s.sum_logprob = e->sum_logprob; s.no_speech = e->no_speech; s.n_finished = e->n_finished;
     s.B = B; s.n_prompt = o.n_prompt; s.sot_index = o.sot_index;
     s.tok_eot = c.tok_eot; s.tok_blank = c.tok_blank; s.tok_no_speech = c.tok_no_speech;
@@ -814,7 +816,7 @@ static SamplerArgs make_sampler(wx_engine* e, int B, const wx_decode_opts& o, in
     return s;
 }
 
-// Sampling decode of B rows with per-row prompts: h_rows [B][n_text_ctx] (prompt ids, rest ignored), h_np / h_sot [B].
+// Sampling decode of B rows with per-row prompts: h_rows [B][n_text_ctx + 1] (prompt ids, rest ignored), h_np / h_sot [B].
 // temperature 0 = greedy.  Shared by wx_decode_greedy (one prompt for every row) and wx_decode_rows.
 static int decode_rows_impl(wx_engine* e, int32_t B, const int32_t* h_rows, const int32_t* h_np, const int32_t* h_sot,
                             const wx_decode_opts* opts, float temperature, uint32_t seed, int32_t* d_tokens, int32_t* d_n_tokens,
@@ -830,7 +832,7 @@ static int decode_rows_impl(wx_engine* e, int32_t B, const int32_t* h_rows, cons
     for (int b = 0; b < B; ++b) {
         if (h_np[b] <= 0 || h_np[b] >= c.n_text_ctx || h_sot[b] < 0 || h_sot[b] >= h_np[b]) return fail(WX_ERR_INVALID, "bad prompt length / sot index");
         for (int i = 0; i < h_np[b]; ++i) {
-            const int32_t id = h_rows[(size_t)b * c.n_text_ctx + i];
+            const int32_t id = h_rows[(size_t)b * e->ld_tok + i];
             if (id < 0 || id >= c.n_vocab) return fail(WX_ERR_INVALID, "prompt id out of range");
         }
         if (h_np[b] > max_np) max_np = h_np[b];
@@ -842,8 +844,8 @@ static int decode_rows_impl(wx_engine* e, int32_t B, const int32_t* h_rows, cons
     hipStream_t st = sc.st;
     // initial state
     {
-        std::vector<int32_t> rows((size_t)B * c.n_text_ctx, c.tok_eot);
-        for (int b = 0; b < B; ++b) memcpy(&rows[(size_t)b * c.n_text_ctx], h_rows + (size_t)b * c.n_text_ctx, (size_t)h_np[b] * 4);
+        std::vector<int32_t> rows((size_t)B * e->ld_tok, c.tok_eot);
+        for (int b = 0; b < B; ++b) memcpy(&rows[(size_t)b * e->ld_tok], h_rows + (size_t)b * e->ld_tok, (size_t)h_np[b] * 4);
         const uint32_t dyn[3] = {0, seed, (uint32_t)sample_len};
         uint32_t dynw[3] = {dyn[0], dyn[1], dyn[2]};
         memcpy(&dynw[0], &temperature, 4);
@@ -858,7 +860,7 @@ static int decode_rows_impl(wx_engine* e, int32_t B, const int32_t* h_rows, cons
     }
     const SamplerArgs sa = make_sampler(e, B, o, 0);
     int total_steps = max_np - 1 + sample_len;     // the longest prompt is fed, then up to sample_len sampling steps
-    if (total_steps > c.n_text_ctx - 1) total_steps = c.n_text_ctx - 1;
+    if (total_steps > c.n_text_ctx) total_steps = c.n_text_ctx;     // positions 0 .. n_text_ctx - 1; the last one fills id n_text_ctx
     hipGraphExec_t exec = nullptr;
     auto capture = [&](hipStream_t cs, auto&& body, hipGraphExec_t* out) -> int {
         hipGraph_t graph = nullptr;
@@ -929,8 +931,8 @@ static int decode_rows_impl(wx_engine* e, int32_t B, const int32_t* h_rows, cons
             }
         }
     }
-    WX_TRY(launch_finish_tokens(e->tokens, c.n_text_ctx, 0, e->row_n_prompt, c.tok_eot, e->d_pos, e->n_tokens, B, st));
-    HIP_TRY(hipMemcpyAsync(d_tokens, e->tokens, (size_t)B * c.n_text_ctx * 4, hipMemcpyDeviceToDevice, st));
+    WX_TRY(launch_finish_tokens(e->tokens, e->ld_tok, 0, e->row_n_prompt, c.tok_eot, e->d_pos, e->n_tokens, B, st));
+    HIP_TRY(hipMemcpyAsync(d_tokens, e->tokens, (size_t)B * e->ld_tok * 4, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_n_tokens, e->n_tokens, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_sum_logprob, e->sum_logprob, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_no_speech_prob, e->no_speech, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
@@ -950,12 +952,12 @@ int wx_decode_greedy(wx_engine* e, int32_t B, const int32_t* h_prompt, const wx_
                      int32_t* d_n_tokens, float* d_sum_logprob, float* d_no_speech_prob, int32_t* h_steps, void* stream) {
     if (!e || !e->finalized) return fail(WX_ERR_STATE, "engine not finalized");
     if (!h_prompt || !opts) return fail(WX_ERR_INVALID, "null argument");
-    const int ctx = e->cfg.n_text_ctx;
+    const int ctx = e->cfg.n_text_ctx, lt = e->ld_tok;
     if (B <= 0 || B > e->cfg.max_batch) return fail(WX_ERR_INVALID, "decode batch exceeds the last wx_encode batch");
     if (opts->n_prompt <= 0 || opts->n_prompt >= ctx || opts->sot_index < 0 || opts->sot_index >= opts->n_prompt)
         return fail(WX_ERR_INVALID, "bad prompt length / sot index");
-    std::vector<int32_t> rows((size_t)B * ctx, e->cfg.tok_eot), np(B, opts->n_prompt), sot(B, opts->sot_index);
-    for (int b = 0; b < B; ++b) memcpy(&rows[(size_t)b * ctx], h_prompt, (size_t)opts->n_prompt * 4);
+    std::vector<int32_t> rows((size_t)B * lt, e->cfg.tok_eot), np(B, opts->n_prompt), sot(B, opts->sot_index);
+    for (int b = 0; b < B; ++b) memcpy(&rows[(size_t)b * lt], h_prompt, (size_t)opts->n_prompt * 4);
     return decode_rows_impl(e, B, rows.data(), np.data(), sot.data(), opts, 0.f, 0, d_tokens, d_n_tokens, d_sum_logprob, d_no_speech_prob,
                             h_steps, stream);
 }
@@ -984,14 +986,14 @@ int wx_decode_beam(wx_engine* e, int32_t B, int32_t beam_size, float patience, c
         return fail(WX_ERR_INVALID, "bad prompt length / sot index");
     for (int i = 0; i < o.n_prompt; ++i) if (h_prompt[i] < 0 || h_prompt[i] >= c.n_vocab) return fail(WX_ERR_INVALID, "prompt id out of range");
     int sample_len = o.max_new_tokens > 0 ? o.max_new_tokens : c.n_text_ctx / 2;
-    if (o.n_prompt + sample_len > c.n_text_ctx) sample_len = c.n_text_ctx - o.n_prompt;
+    if (o.n_prompt + sample_len > e->ld_tok) sample_len = e->ld_tok - o.n_prompt;     // upstream stops once a row holds n_text_ctx + 1 ids
     if (o.check_interval < 1) o.check_interval = 8;
     StreamScope sc(e, stream);
     hipStream_t st = sc.st;
     e->beam_n = n;
     {
-        std::vector<int32_t> rows((size_t)R * c.n_text_ctx, c.tok_eot), node((size_t)R * c.n_text_ctx, 0);
-        for (int r = 0; r < R; ++r) { memcpy(&rows[(size_t)r * c.n_text_ctx], h_prompt, (size_t)o.n_prompt * 4); node[(size_t)r * c.n_text_ctx] = r; }
+        std::vector<int32_t> rows((size_t)R * e->ld_tok, c.tok_eot), node((size_t)R * c.n_text_ctx, 0);
+        for (int r = 0; r < R; ++r) { memcpy(&rows[(size_t)r * e->ld_tok], h_prompt, (size_t)o.n_prompt * 4); node[(size_t)r * c.n_text_ctx] = r; }
         HIP_TRY(hipMemcpyAsync(e->tokens, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(e->b_node, node.data(), node.size() * 4, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemsetAsync(e->d_pos, 0, 64, st));
@@ -999,13 +1001,13 @@ int wx_decode_beam(wx_engine* e, int32_t B, int32_t beam_size, float patience, c
         HIP_TRY(hipMemsetAsync(e->no_speech, 0, (size_t)B * 4, st));
         HIP_TRY(hipMemsetAsync(e->b_fin_count, 0, (size_t)B * 4, st));
         HIP_TRY(hipMemsetAsync(e->b_fin_score, 0, (size_t)B * maxc * 4, st));
-        std::vector<int32_t> fin((size_t)B * maxc * c.n_text_ctx, c.tok_eot);
+        std::vector<int32_t> fin((size_t)B * maxc * e->ld_tok, c.tok_eot);
         HIP_TRY(hipMemcpyAsync(e->b_fin_tokens, fin.data(), fin.size() * 4, hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
     BeamArgs ba;
     ba.logits = e->logits; ba.ldl = e->vocab_pad; ba.n_vocab = c.n_vocab;
-    ba.tokens = e->tokens; ba.tokens_tmp = e->b_tokens_tmp; ba.ld_tok = c.n_text_ctx;
+    ba.tokens = e->tokens; ba.tokens_tmp = e->b_tokens_tmp; ba.ld_tok = e->ld_tok; ba.ld_node = c.n_text_ctx;
     ba.node = e->b_node; ba.node_tmp = e->b_node_tmp;
     ba.sum_logprob = e->sum_logprob; ba.sum_tmp = e->b_sum_tmp;
     ba.cand_score = e->b_cand_score; ba.cand_tok = e->b_cand_tok; ba.src = e->b_src; ba.next_tok = e->b_next;
@@ -1055,10 +1057,10 @@ int wx_decode_beam(wx_engine* e, int32_t B, int32_t beam_size, float patience, c
             }
         }
     }
-    HIP_TRY(hipMemcpyAsync(d_fin_tokens, e->b_fin_tokens, (size_t)B * maxc * c.n_text_ctx * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_fin_tokens, e->b_fin_tokens, (size_t)B * maxc * e->ld_tok * 4, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_fin_sum_logprob, e->b_fin_score, (size_t)B * maxc * 4, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_fin_count, e->b_fin_count, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_beam_tokens, e->tokens, (size_t)R * c.n_text_ctx * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_beam_tokens, e->tokens, (size_t)R * e->ld_tok * 4, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_beam_sum_logprob, e->sum_logprob, (size_t)R * 4, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_no_speech_prob, e->no_speech, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
     if (h_steps) *h_steps = sampled;
@@ -1080,7 +1082,7 @@ int wx_decoder_logits(wx_engine* e, int32_t B, const int32_t* d_tokens, int32_t 
     e->beam_n = 0;
     StreamScope sc(e, stream);
     hipStream_t st = sc.st;
-    HIP_TRY(hipMemcpy2DAsync(e->tokens, (size_t)c.n_text_ctx * 4, d_tokens, (size_t)n * 4, (size_t)n * 4, B, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpy2DAsync(e->tokens, (size_t)e->ld_tok * 4, d_tokens, (size_t)n * 4, (size_t)n * 4, B, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemsetAsync(e->d_pos, 0, 64, st));
     wx_decode_opts o{};
     o.n_prompt = n; o.sot_index = 0; o.without_timestamps = 1; o.suppress_blank = 0; o.max_initial_timestamp_index = -1;

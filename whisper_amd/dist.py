@@ -124,7 +124,7 @@ def transcribe_sharded(engine, audio: np.ndarray, prompt: Sequence[int], group=N
     else:
         local = {"tokens": [], "sum_logprobs": [], "no_speech_probs": [], "steps": 0}
     per = shard_range(nw, 0, world)[1]
-    out = gather_results(local, max(per, 1), engine.dims.n_text_ctx, engine.tok.eot, engine.torch_device, group)
+    out = gather_results(local, max(per, 1), engine.dims.n_text_ctx + 1, engine.tok.eot, engine.torch_device, group)
     out["n_windows"] = nw
     out["local_windows"] = (w_lo, w_hi)
     out["steps"] = local.get("steps", 0)

@@ -195,7 +195,7 @@ class WhisperEngine:
             max_initial_timestamp_index=int(max_initial_timestamp_index), use_graph=int(use_graph),
             check_interval=int(check_interval), profile_stride=int(profile_stride))
         dev = self.torch_device
-        tokens = torch.empty((B, self.dims.n_text_ctx), dtype=torch.int32, device=dev)
+        tokens = torch.empty((B, self.dims.n_text_ctx + 1), dtype=torch.int32, device=dev)    # ids per row: n_text_ctx + 1
         n_tokens = torch.empty(B, dtype=torch.int32, device=dev)
         sum_lp = torch.empty(B, dtype=torch.float32, device=dev)
         nsp = torch.empty(B, dtype=torch.float32, device=dev)
@@ -211,7 +211,7 @@ class WhisperEngine:
                     use_graph: bool = True, check_interval: int = 8) -> Dict[str, object]:
         """Sampling decode with one prompt per window of the last encode (``len(prompts)`` rows); ``temperature`` 0 is
         greedy.  Returns per-row token lists (after each row's own prompt, EOT excluded), sum_logprobs, no_speech_probs."""
-        B, ctx = len(prompts), self.dims.n_text_ctx
+        B, ctx = len(prompts), self.dims.n_text_ctx + 1                        # ids per row (include/whisper_amd.h)
         rows = np.full((B, ctx), self.tok.eot, np.int32)
         n_prompt = np.zeros(B, np.int32); sot = np.zeros(B, np.int32)
         for b, p in enumerate(prompts):
@@ -248,7 +248,7 @@ class WhisperEngine:
             without_timestamps=int(without_timestamps), suppress_blank=int(suppress_blank),
             max_initial_timestamp_index=int(max_initial_timestamp_index), use_graph=int(use_graph),
             check_interval=int(check_interval), profile_stride=0)
-        dev, n, ctx = self.torch_device, int(beam_size), self.dims.n_text_ctx
+        dev, n, ctx = self.torch_device, int(beam_size), self.dims.n_text_ctx + 1   # ids per row
         maxc = int(round(n * patience))
         fin_t = torch.empty((B, maxc, ctx), dtype=torch.int32, device=dev)
         fin_s = torch.empty((B, maxc), dtype=torch.float32, device=dev)
