@@ -99,10 +99,10 @@ __device__ __forceinline__ void load_head_rows(const AttnArgs& a, int b, int h, 
 // heads per workgroup, so a batch-64 launch is 320 workgroups that are all resident at once.  Round trip 1 fetches
 // everything that depends on no other load (position, page-table row, q/k/v partial tiles); round trip 2 is the K/V
 // stream: <= 448 keys, 64 keys (8 KiB K + 8 KiB V in bf16) per iteration in flight per wave.
-template <typename T, int NWH, int HPB = 4>
+template <typename T, int NWH, int HPB = 4, int U = 8, bool GROUPED = false>
 __global__ __launch_bounds__(64 * HPB * NWH) void attn_self_decode_kernel(AttnArgs a) {
     typedef Chunk<T> C;
-    constexpr int EPL = C::EPL, LPK = HEAD_DIM / EPL, KPI = 64 / LPK, U = 8, IT = KPI * U;
+    constexpr int EPL = C::EPL, LPK = HEAD_DIM / EPL, KPI = 64 / LPK, IT = KPI * U;
     __shared__ float s_row[HPB][3][HEAD_DIM];
     __shared__ int s_pt[HPB][448];                 // page-table row (page size 16: 28 entries; page size 1: n_text_ctx)
     __shared__ float s_m[HPB][NWH], s_l[HPB][NWH];
@@ -116,9 +116,9 @@ __global__ __launch_bounds__(64 * HPB * NWH) void attn_self_decode_kernel(AttnAr
     const int sub = lane % LPK, grp = lane / LPK;
     // prompt pass (q_group > 1): row b is position *d_pos + b % q_group of sequence b / q_group, whose k/v rows are already
     // in the cache (launch_kv_append ran first): nothing is appended or patched here
-    const bool single = a.q_group == 1;
-    const int seq = b / a.q_group;
-    const int t_cur = *a.d_pos + b % a.q_group, n_keys = t_cur + 1;
+    constexpr bool single = !GROUPED;
+    const int seq = GROUPED ? b / a.q_group : b;
+    const int t_cur = *a.d_pos + (GROUPED ? b % a.q_group : 0), n_keys = t_cur + 1;
     const int PS = a.page_size;
     if (kw == 0) {
         for (int i = lane; i < a.pt_ld; i += 64) s_pt[hs][i] = a.page_table[seq * a.pt_ld + i];
@@ -145,18 +145,21 @@ __global__ __launch_bounds__(64 * HPB * NWH) void attn_self_decode_kernel(AttnAr
     const int total_it = (n_keys + IT - 1) / IT;
     for (int it = kw; it < total_it; it += NWH) {
         typename C::Raw kr[U], vr[U];
-        const int key0 = it * IT + grp;
+        {
+            const int key0 = it * IT + grp;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            int key = key0 + u * KPI;
-            if (key > n_keys - 1) key = n_keys - 1;
-            // the slot of position t_cur is being written by this launch: it is read (address valid, value ignored)
-            // and replaced by the register copy
-            const int64_t off = (((int64_t)s_pt[hs][key / PS] * a.H + h) * PS + key % PS) * HEAD_DIM + sub * EPL;
-            kr[u] = __builtin_nontemporal_load(reinterpret_cast<const typename C::Raw*>(Kp + off));
-            vr[u] = __builtin_nontemporal_load(reinterpret_cast<const typename C::Raw*>(Vp + off));
-            if (single && key == t_cur) { kr[u] = kn_r; vr[u] = vn_r; }
+            for (int u = 0; u < U; ++u) {
+                int key = key0 + u * KPI;
+                if (key > n_keys - 1) key = n_keys - 1;
+                // the slot of position t_cur is being written by this launch: it is read (address valid, value ignored)
+                // and replaced by the register copy
+                const int64_t off = (((int64_t)s_pt[hs][key / PS] * a.H + h) * PS + key % PS) * HEAD_DIM + sub * EPL;
+                kr[u] = __builtin_nontemporal_load(reinterpret_cast<const typename C::Raw*>(Kp + off));
+                vr[u] = __builtin_nontemporal_load(reinterpret_cast<const typename C::Raw*>(Vp + off));
+                if (single && key == t_cur) { kr[u] = kn_r; vr[u] = vn_r; }
+            }
         }
+        const int key0 = it * IT + grp;
         float s[U];
         float mt = -INFINITY;
 #pragma unroll
@@ -510,10 +513,16 @@ int launch_attn_decode(const AttnArgs& a, hipStream_t st) {
     if (paged) {
         if (a.q_group < 1 || a.B % a.q_group || (a.q_group > 1 && a.page_size != KV_PAGE)) return -1;
         if (!a.d_pos || !a.Kpool || !a.Vpool || a.pt_ld > 448 || (a.page_size != 1 && a.page_size != KV_PAGE) || a.n_split != 1 || (!a.q_partial && (!a.Knew || !a.Vnew))) return -1;
-        // 2 waves per head x 4 heads per workgroup measured best over {1,2,4} x {1,2,4,8} (tools/microbench): fewer, fatter
-        // workgroups lose at long histories, more workgroups pay ~5 ns of dispatch each at short ones
         dim3 grid((a.B * a.H + 3) / 4);
-        if (a.dt == DT_BF16) hipLaunchKernelGGL((attn_self_decode_kernel<bf16, 2>), grid, dim3(512), 0, st, a);
+        // bf16: 2 waves per head, 2 heads per workgroup (640 workgroups of 256 threads at batch 64), 16 keys per
+        // wave-iteration.  Swept over waves/head x heads/workgroup x keys/iteration, with and without a software-pipelined
+        // load (tools/microbench, t = 8 / 64 / 224 / 440): 4 heads x 64 keys 9.5 / 13.5 / 22.6 / 35.4 us, this shape
+        // 6.1 / 9.4 / 17.4 / 27.7 us; pipelining the loads changes nothing once the iterations are this fine.  The grouped
+        // (prompt pass) variant is a separate instantiation so the per-token step carries no index arithmetic for it.
+        const dim3 grid2((a.B * a.H + 1) / 2);
+        if (a.dt == DT_BF16 && a.q_group == 1) hipLaunchKernelGGL((attn_self_decode_kernel<bf16, 2, 2, 2, false>), grid2, dim3(256), 0, st, a);
+        else if (a.dt == DT_BF16) hipLaunchKernelGGL((attn_self_decode_kernel<bf16, 2, 2, 2, true>), grid2, dim3(256), 0, st, a);
+        else if (a.q_group > 1) hipLaunchKernelGGL((attn_self_decode_kernel<float, 2, 4, 8, true>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((attn_self_decode_kernel<float, 2>), grid, dim3(512), 0, st, a);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
