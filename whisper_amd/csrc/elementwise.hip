@@ -2,6 +2,7 @@
 // log-softmax bookkeeping) for gfx950.  All of these are HBM/L2-bound streaming kernels: 16-byte vector accesses,
 // one wave per row where a row reduction is needed.
 #include "common.h"
+#include <cstdlib>
 
 namespace wx {
 
@@ -74,27 +75,27 @@ int launch_layernorm(const float* x, const float* gamma, const float* beta, void
 // result is deterministic), then the next sub-layer's LayerNorm of the updated row.  One WORKGROUP per row (a decode
 // batch has <= 64 rows, and a CU sustains only ~25 GB/s of loads: the n_split*d*4 bytes of a row are spread over as
 // many CUs as there are rows), 16 B per lane, two-pass statistics through LDS.
-template <typename TO>
-__global__ __launch_bounds__(256) void reduce_layernorm_kernel(float* __restrict__ x, const float* __restrict__ partial, int n_split,
-                                                               const float* __restrict__ bias, const float* __restrict__ gamma,
-                                                               const float* __restrict__ beta, TO* __restrict__ out, int rows, int d) {
-    constexpr int MAXV = 2;                       // d <= 256 * 4 * 2 = 2048
-    constexpr int MAX_SPLIT = 16;
-    __shared__ float red[8];
+template <typename TO, int NT, int MAX_SPLIT>
+__global__ __launch_bounds__(NT) void reduce_layernorm_kernel(float* __restrict__ x, const float* __restrict__ partial, int n_split,
+                                                              const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, TO* __restrict__ out, int rows, int d) {
+    constexpr int MAXV = (2048 + NT * 4 - 1) / (NT * 4);       // d <= 2048; NT = 384 covers d <= 1536 with one chunk per lane
+    constexpr int NW = NT / 64;                                // MAX_SPLIT: partial tiles fetched per chunk (>= n_split)
+    __shared__ float red[2 * NW];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, row = blockIdx.x;
     f32x4* xr = reinterpret_cast<f32x4*>(x + (int64_t)row * d);
     const int nv = d / 4;
     f32x4 v[MAXV];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int c = tid + i * 256;
+        const int c = tid + i * NT;
         v[i] = (c < nv) ? xr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (n_split > 0) {
         const f32x4* br = reinterpret_cast<const f32x4*>(bias);
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
-            const int c = tid + i * 256;
+            const int c = tid + i * NT;
             if (c < nv) {
                 // all partial tiles in flight at once: a runtime-bounded loop would serialise n_split round trips.
                 // Loads past n_split are clamped to the last tile and not added (no load under a branch).
@@ -119,11 +120,14 @@ __global__ __launch_bounds__(256) void reduce_layernorm_kernel(float* __restrict
     for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
     if (lane == 0) red[wid] = sum;
     __syncthreads();
-    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)d;
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tot += red[w];
+    const float mean = tot / (float)d;
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int c = tid + i * 256;
+        const int c = tid + i * NT;
         if (c < nv) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { const float t = v[i][j] - mean; sq = fmaf(t, t, sq); }
@@ -131,14 +135,17 @@ __global__ __launch_bounds__(256) void reduce_layernorm_kernel(float* __restrict
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off);
-    if (lane == 0) red[4 + wid] = sq;
+    if (lane == 0) red[NW + wid] = sq;
     __syncthreads();
-    const float rstd = 1.0f / sqrtf(((red[4] + red[5]) + (red[6] + red[7])) / (float)d + 1e-5f);
+    float tsq = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tsq += red[NW + w];
+    const float rstd = 1.0f / sqrtf(tsq / (float)d + 1e-5f);
     const f32x4* gr = reinterpret_cast<const f32x4*>(gamma);
     const f32x4* be = reinterpret_cast<const f32x4*>(beta);
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int c = tid + i * 256;
+        const int c = tid + i * NT;
         if (c < nv) {
             const f32x4 gg = gr[c], bb = be[c];
             f32x4 y;
@@ -160,8 +167,16 @@ int launch_reduce_layernorm(float* x, const float* partial, int n_split, const f
                             void* out, int out_dtype, int rows, int d, hipStream_t st) {
     if (d % 4 != 0 || d > 2048 || rows <= 0 || n_split < 0 || n_split > 16 || (n_split > 0 && (!partial || !bias))) return -1;
     const int blocks = rows;
-    if (out_dtype == DT_F32) hipLaunchKernelGGL(reduce_layernorm_kernel<float>, dim3(blocks), dim3(256), 0, st, x, partial, n_split, bias, gamma, beta, (float*)out, rows, d);
-    else hipLaunchKernelGGL(reduce_layernorm_kernel<bf16>, dim3(blocks), dim3(256), 0, st, x, partial, n_split, bias, gamma, beta, (bf16*)out, rows, d);
+    // one 16-B chunk per lane when the row fits 384 lanes (d = 1280): half as many loads per lane as with 256
+    static const int nt_env = getenv("WX_RLN_NT") ? atoi(getenv("WX_RLN_NT")) : 0;
+    const bool wide = (nt_env ? nt_env == 384 : true) && d > 1024 && d <= 1536;
+#define WX_RLN_LAUNCH(TO_, NT_, MS_) hipLaunchKernelGGL((reduce_layernorm_kernel<TO_, NT_, MS_>), dim3(blocks), dim3(NT_), 0, st, x, partial, n_split, bias, gamma, beta, (TO_*)out, rows, d)
+#define WX_RLN_SPLIT(TO_, NT_) do { if (n_split <= 4) WX_RLN_LAUNCH(TO_, NT_, 4); else if (n_split <= 10) WX_RLN_LAUNCH(TO_, NT_, 10); else WX_RLN_LAUNCH(TO_, NT_, 16); } while (0)
+    // as few clamped (wasted) tile loads as the split allows: 4, 10 or 16 per chunk
+    if (wide) { if (out_dtype == DT_F32) WX_RLN_SPLIT(float, 384); else WX_RLN_SPLIT(bf16, 384); }
+    else { if (out_dtype == DT_F32) WX_RLN_SPLIT(float, 256); else WX_RLN_SPLIT(bf16, 256); }
+#undef WX_RLN_SPLIT
+#undef WX_RLN_LAUNCH
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
