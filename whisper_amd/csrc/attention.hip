@@ -70,22 +70,31 @@ template <int E> __device__ __forceinline__ void merge_state(float& m, float& l,
 // query (and, for self-attention, this step's key/value row) of head h of sequence b for lane `lane`: element `lane` of
 // each 64-wide row, either read directly or assembled from the projection GEMM's split-K partial tiles (fixed order,
 // all tiles in flight at once: loads past q_nsplit are clamped to the last tile and not added).
+template <typename T, int NROWS, int MS>
+__device__ __forceinline__ void load_head_rows_ms(const AttnArgs& a, int b, int h, int lane, float (&out)[NROWS]) {
+    const int dm = a.H * HEAD_DIM;
+#pragma unroll
+    for (int which = 0; which < NROWS; ++which) {
+        const int col = which * dm + h * HEAD_DIM + lane;
+        float pt[MS];
+#pragma unroll
+        for (int s = 0; s < MS; ++s) pt[s] = a.q_partial[((int64_t)(s < a.q_nsplit ? s : a.q_nsplit - 1) * a.B + b) * a.q_sb + col];
+        float v = a.q_bias[col];
+#pragma unroll
+        for (int s = 0; s < MS; ++s) if (s < a.q_nsplit) v += pt[s];
+        if (which < 2) v *= a.q_scale;        // q and k carry head_dim^-0.25; v does not
+        out[which] = (float)(T)v;            // same rounding point as a stored q/k/v row
+    }
+}
+
 template <typename T, int NROWS>
 __device__ __forceinline__ void load_head_rows(const AttnArgs& a, int b, int h, int lane, float (&out)[NROWS]) {
     if (a.q_partial) {
-        const int dm = a.H * HEAD_DIM;
-#pragma unroll
-        for (int which = 0; which < NROWS; ++which) {
-            const int col = which * dm + h * HEAD_DIM + lane;
-            float pt[16];
-#pragma unroll
-            for (int s = 0; s < 16; ++s) pt[s] = a.q_partial[((int64_t)(s < a.q_nsplit ? s : a.q_nsplit - 1) * a.B + b) * a.q_sb + col];
-            float v = a.q_bias[col];
-#pragma unroll
-            for (int s = 0; s < 16; ++s) if (s < a.q_nsplit) v += pt[s];
-            if (which < 2) v *= a.q_scale;        // q and k carry head_dim^-0.25; v does not
-            out[which] = (float)(T)v;            // same rounding point as a stored q/k/v row
-        }
+        // every load costs issue time even when it is a clamped duplicate: fetch 4, 10 or 16 tiles, whichever covers the
+        // split (uniform branch on a kernel argument)
+        if (a.q_nsplit <= 4) load_head_rows_ms<T, NROWS, 4>(a, b, h, lane, out);
+        else if (a.q_nsplit <= 10) load_head_rows_ms<T, NROWS, 10>(a, b, h, lane, out);
+        else load_head_rows_ms<T, NROWS, 16>(a, b, h, lane, out);
     } else {
         out[0] = (float)reinterpret_cast<const T*>(a.Q)[(int64_t)b * a.q_sb + h * a.q_sh + lane];
         if (NROWS > 1) {
