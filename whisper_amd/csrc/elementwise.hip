@@ -163,6 +163,79 @@ __global__ __launch_bounds__(NT) void reduce_layernorm_kernel(float* __restrict_
     }
 }
 
+// Same reduce + LayerNorm with TWO lanes per 16-B chunk (lanes l and l + 32 of a wave): each fetches half of the partial
+// tiles, one shuffle joins them.  Halves the loads per lane again (7 instead of 12 at split 10); 32 chunks per wave.
+template <typename TO, int NW, int HS>       // NW waves (32 * NW chunks >= d / 4), HS = tiles per half (>= ceil(n_split / 2))
+__global__ __launch_bounds__(NW * 64) void reduce_layernorm2_kernel(float* __restrict__ x, const float* __restrict__ partial, int n_split,
+                                                                    const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, TO* __restrict__ out, int rows, int d) {
+    __shared__ float red[2 * NW];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, row = blockIdx.x;
+    const int half = lane >> 5, c = wid * 32 + (lane & 31), nv = d / 4;
+    const bool live = c < nv;
+    const int cc = live ? c : nv - 1;
+    const int h0 = (n_split + 1) / 2;                      // tiles 0 .. h0-1 on half 0, h0 .. n_split-1 on half 1
+    const int s_lo = half ? h0 : 0, s_n = half ? n_split - h0 : h0;
+    f32x4 pt[HS];
+#pragma unroll
+    for (int s = 0; s < HS; ++s) {
+        int sc = s_lo + (s < s_n ? s : s_n - 1); if (sc > n_split - 1) sc = n_split - 1; if (sc < 0) sc = 0;
+        pt[s] = reinterpret_cast<const f32x4*>(partial + ((int64_t)sc * rows + row) * d)[cc];
+    }
+    // half 0 also carries the residual row, half 1 the bias
+    const f32x4 extra = half ? reinterpret_cast<const f32x4*>(bias)[cc] : reinterpret_cast<const f32x4*>(x + (int64_t)row * d)[cc];
+    f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < HS; ++s) if (s < s_n) t += pt[s];
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = __shfl_xor(t[j], 32);
+    f32x4 e2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e2[j] = __shfl_xor(extra[j], 32);
+    // v = x + ((tiles of half 0 + tiles of half 1) + bias), the same expression on both lanes
+    const f32x4 t0 = half ? o : t, t1 = half ? t : o, xv = half ? e2 : extra, bv = half ? extra : e2;
+    f32x4 v = xv + ((t0 + t1) + bv);
+    if (!live) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (live && half == 0) reinterpret_cast<f32x4*>(x + (int64_t)row * d)[c] = v;
+    float sum = half == 0 ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    if (lane == 0) red[wid] = sum;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tot += red[w];
+    const float mean = tot / (float)d;
+    float sq = 0.f;
+    if (live && half == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float u = v[j] - mean; sq = fmaf(u, u, sq); }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off);
+    if (lane == 0) red[NW + wid] = sq;
+    __syncthreads();
+    float tsq = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tsq += red[NW + w];
+    const float rstd = 1.0f / sqrtf(tsq / (float)d + 1e-5f);
+    if (live && half == 1) {
+        const f32x4 gg = reinterpret_cast<const f32x4*>(gamma)[c], bb = reinterpret_cast<const f32x4*>(beta)[c];
+        f32x4 y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = (v[j] - mean) * rstd * gg[j] + bb[j];
+        if constexpr (sizeof(TO) == 4) {
+            reinterpret_cast<f32x4*>(out + (int64_t)row * d)[c] = y;
+        } else {
+            bf16x4 ob;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ob[j] = (bf16)y[j];
+            reinterpret_cast<bf16x4*>(out + (int64_t)row * d)[c] = ob;
+        }
+    }
+}
+
 int launch_reduce_layernorm(float* x, const float* partial, int n_split, const float* bias, const float* gamma, const float* beta,
                             void* out, int out_dtype, int rows, int d, hipStream_t st) {
     if (d % 4 != 0 || d > 2048 || rows <= 0 || n_split < 0 || n_split > 16 || (n_split > 0 && (!partial || !bias))) return -1;
@@ -172,6 +245,18 @@ int launch_reduce_layernorm(float* x, const float* partial, int n_split, const f
     const bool wide = (nt_env ? nt_env == 384 : true) && d > 1024 && d <= 1536;
 #define WX_RLN_LAUNCH(TO_, NT_, MS_) hipLaunchKernelGGL((reduce_layernorm_kernel<TO_, NT_, MS_>), dim3(blocks), dim3(NT_), 0, st, x, partial, n_split, bias, gamma, beta, (TO_*)out, rows, d)
 #define WX_RLN_SPLIT(TO_, NT_) do { if (n_split <= 4) WX_RLN_LAUNCH(TO_, NT_, 4); else if (n_split <= 10) WX_RLN_LAUNCH(TO_, NT_, 10); else WX_RLN_LAUNCH(TO_, NT_, 16); } while (0)
+    // bf16 decode path: two lanes per chunk (3.64 -> 3.20 us at d = 1280, split 10); WX_RLN1=1 keeps one lane per chunk
+    static const bool one_lane = getenv("WX_RLN1") != nullptr;
+    if (!one_lane && out_dtype == DT_BF16 && n_split >= 2 && n_split <= 10 && d <= 1280) {
+#define WX_RLN2_LAUNCH(NW_) do { \
+        if (n_split <= 4) hipLaunchKernelGGL((reduce_layernorm2_kernel<bf16, NW_, 2>), dim3(blocks), dim3(NW_ * 64), 0, st, x, partial, n_split, bias, gamma, beta, (bf16*)out, rows, d); \
+        else hipLaunchKernelGGL((reduce_layernorm2_kernel<bf16, NW_, 5>), dim3(blocks), dim3(NW_ * 64), 0, st, x, partial, n_split, bias, gamma, beta, (bf16*)out, rows, d); } while (0)
+        const int nv = d / 4;
+        if (nv <= 32 * 3) WX_RLN2_LAUNCH(3); else if (nv <= 32 * 4) WX_RLN2_LAUNCH(4); else if (nv <= 32 * 6) WX_RLN2_LAUNCH(6);
+        else if (nv <= 32 * 8) WX_RLN2_LAUNCH(8); else WX_RLN2_LAUNCH(10);
+#undef WX_RLN2_LAUNCH
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     // as few clamped (wasted) tile loads as the split allows: 4, 10 or 16 per chunk
     if (wide) { if (out_dtype == DT_F32) WX_RLN_SPLIT(float, 384); else WX_RLN_SPLIT(bf16, 384); }
     else { if (out_dtype == DT_F32) WX_RLN_SPLIT(float, 256); else WX_RLN_SPLIT(bf16, 256); }
@@ -186,13 +271,19 @@ __global__ __launch_bounds__(256) void reduce_bias_gelu_kernel(const float* __re
                                                                const float* __restrict__ bias, bf16* __restrict__ out, int64_t total4, int N) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total4) return;
-    f32x4 pt[4];
+    f32x4 v;
+    if (n_split == 2) {           // the usual case (fc1 at d = 1280): exactly two loads, none clamped
+        const f32x4 p0 = reinterpret_cast<const f32x4*>(partial)[i], p1 = reinterpret_cast<const f32x4*>(partial + split_stride)[i];
+        v = p0 + p1;
+    } else {
+        f32x4 pt[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) pt[s] = reinterpret_cast<const f32x4*>(partial + (s < n_split ? s : n_split - 1) * split_stride)[i];
-    f32x4 v = pt[0];
+        for (int s = 0; s < 4; ++s) pt[s] = reinterpret_cast<const f32x4*>(partial + (s < n_split ? s : n_split - 1) * split_stride)[i];
+        v = pt[0];
 #pragma unroll
-    for (int s = 1; s < 4; ++s) if (s < n_split) v += pt[s];
-    for (int s = 4; s < n_split; ++s) v += reinterpret_cast<const f32x4*>(partial + s * split_stride)[i];
+        for (int s = 1; s < 4; ++s) if (s < n_split) v += pt[s];
+        for (int s = 4; s < n_split; ++s) v += reinterpret_cast<const f32x4*>(partial + s * split_stride)[i];
+    }
     v += *reinterpret_cast<const f32x4*>(bias + (i * 4) % N);
     bf16x4 o;
 #pragma unroll
