@@ -241,8 +241,7 @@ int launch_reduce_layernorm(float* x, const float* partial, int n_split, const f
     if (d % 4 != 0 || d > 2048 || rows <= 0 || n_split < 0 || n_split > 16 || (n_split > 0 && (!partial || !bias))) return -1;
     const int blocks = rows;
     // one 16-B chunk per lane when the row fits 384 lanes (d = 1280): half as many loads per lane as with 256
-    static const int nt_env = getenv("WX_RLN_NT") ? atoi(getenv("WX_RLN_NT")) : 0;
-    const bool wide = (nt_env ? nt_env == 384 : true) && d > 1024 && d <= 1536;
+    const bool wide = d > 1024 && d <= 1536;
 #define WX_RLN_LAUNCH(TO_, NT_, MS_) hipLaunchKernelGGL((reduce_layernorm_kernel<TO_, NT_, MS_>), dim3(blocks), dim3(NT_), 0, st, x, partial, n_split, bias, gamma, beta, (TO_*)out, rows, d)
 #define WX_RLN_SPLIT(TO_, NT_) do { if (n_split <= 4) WX_RLN_LAUNCH(TO_, NT_, 4); else if (n_split <= 10) WX_RLN_LAUNCH(TO_, NT_, 10); else WX_RLN_LAUNCH(TO_, NT_, 16); } while (0)
     // bf16 decode path: two lanes per chunk (3.64 -> 3.20 us at d = 1280, split 10); WX_RLN1=1 keeps one lane per chunk
