@@ -206,6 +206,18 @@ GemmArgs gemm_basic(wx_engine* e, const void* A, int64_t lda, const void* W, int
     return g;
 }
 
+// Every hot entry point runs with the ENGINE's device current and restores the caller's on the way out: a process that
+// drives several GPUs (or never called hipSetDevice / torch.cuda.set_device for this one) must not launch on, or allocate
+// from, the wrong device.
+struct DeviceScope {
+    int prev = -1, dev;
+    explicit DeviceScope(const wx_engine* e) : dev(e->cfg.device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceScope() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+};
+
 struct StreamScope {   // graph capture needs a real stream: route NULL-stream callers through the engine's own stream
     wx_engine* e; hipStream_t user, st; bool swapped;
     StreamScope(wx_engine* e_, void* s) : e(e_), user((hipStream_t)s), st((hipStream_t)s), swapped(false) {
@@ -237,9 +249,14 @@ int wx_create(const wx_config* cfg, wx_engine** out) {
     if (c.n_text_ctx % KV_PAGE || c.n_text_ctx <= 0 || c.n_mels <= 0 || c.n_mels > 256 || c.max_batch <= 0 || c.n_vocab <= 0)
         return fail(WX_ERR_INVALID, "bad dimensions");
     if (c.precision != WX_PREC_F32 && c.precision != WX_PREC_BF16) return fail(WX_ERR_INVALID, "bad precision");
-    HIP_TRY(hipSetDevice(c.device));
+    {   // the device must exist; streams and events below are created on it
+        int n_dev = 0;
+        HIP_TRY(hipGetDeviceCount(&n_dev));
+        if (c.device < 0 || c.device >= n_dev) return fail(WX_ERR_INVALID, "no such device");
+    }
     wx_engine* e = new wx_engine();
     e->cfg = c;
+    DeviceScope dev_scope(e);
     e->dt = c.precision == WX_PREC_BF16 ? DT_BF16 : DT_F32;
     e->d = c.n_audio_state; e->H = c.n_audio_head; e->dt_ = c.n_text_state; e->Ht = c.n_text_head;
     e->c_pad = (c.n_mels + 63) / 64 * 64;
@@ -258,7 +275,7 @@ int wx_create(const wx_config* cfg, wx_engine** out) {
 
 void wx_destroy(wx_engine* e) {
     if (!e) return;
-    (void)hipSetDevice(e->cfg.device);
+    DeviceScope dev_scope(e);
     (void)hipDeviceSynchronize();
     if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
     for (hipEvent_t ev : e->prof_events) (void)hipEventDestroy(ev);
@@ -304,7 +321,7 @@ int wx_finalize(wx_engine* e) {
     if (!e) return fail(WX_ERR_INVALID, "null engine");
     if (e->finalized) return fail(WX_ERR_STATE, "engine already finalized");
     if (e->mel_filters_h.empty()) return fail(WX_ERR_STATE, "mel filters not set");
-    HIP_TRY(hipSetDevice(e->cfg.device));
+    DeviceScope dev_scope(e);
     const wx_config& c = e->cfg;
     const int d = e->d, B = c.max_batch, T = e->T;
     const size_t es = dtype_size(e->dt);
@@ -469,6 +486,7 @@ int wx_finalize(wx_engine* e) {
 
 int wx_pcm16_to_f32(wx_engine* e, const int16_t* d_pcm16, int64_t n, float* d_out, void* stream) {
     if (!e || !d_pcm16 || !d_out || n < 0) return fail(WX_ERR_INVALID, "bad argument");
+    DeviceScope dev_scope(e);
     WX_TRY(launch_pcm16_to_f32(d_pcm16, d_out, n, (hipStream_t)stream));
     return WX_OK;
 }
@@ -476,6 +494,7 @@ int wx_pcm16_to_f32(wx_engine* e, const int16_t* d_pcm16, int64_t n, float* d_ou
 int wx_resample_pcm16(wx_engine* e, const int16_t* d_pcm16, int64_t n_frames, int32_t n_channels, int32_t up, int32_t down,
                       const float* h_taps, int32_t half_len, int32_t quantize, float* d_out, int64_t n_out, void* stream) {
     if (!e || !e->finalized) return fail(WX_ERR_STATE, "engine not finalized");
+    DeviceScope dev_scope(e);
     if (!d_pcm16 || !h_taps || !d_out || n_frames <= 0) return fail(WX_ERR_INVALID, "bad argument");
     if (n_channels < 1 || n_channels > 8) return fail(WX_ERR_INVALID, "n_channels must be 1..8");
     if (up < 1 || down < 1 || down > 8 * up) return fail(WX_ERR_INVALID, "unsupported rate ratio (down <= 8*up)");
@@ -492,6 +511,7 @@ int wx_resample_pcm16(wx_engine* e, const int16_t* d_pcm16, int64_t n_frames, in
 
 int wx_mel_reset_max(wx_engine* e, float* d_max, void* stream) {
     if (!e || !d_max) return fail(WX_ERR_INVALID, "bad argument");
+    DeviceScope dev_scope(e);
     WX_TRY(launch_fill_f32(d_max, -INFINITY, 1, (hipStream_t)stream));
     return WX_OK;
 }
@@ -499,6 +519,7 @@ int wx_mel_reset_max(wx_engine* e, float* d_max, void* stream) {
 int wx_mel_stage1(wx_engine* e, const float* d_pcm, int64_t pcm_offset, int64_t n_valid, int64_t n_file, int64_t n_total,
                   int64_t frame0, int64_t n_frames, float* d_logmel, int64_t ld, float* d_max, void* stream) {
     if (!e || !e->finalized) return fail(WX_ERR_STATE, "engine not finalized");
+    DeviceScope dev_scope(e);
     if (!d_pcm || !d_logmel || !d_max || n_frames < 0 || frame0 < 0 || n_file < 0 || n_total < n_file || n_valid < 0 || ld < n_frames)
         return fail(WX_ERR_INVALID, "bad mel arguments");
     if (n_total < N_FFT) return fail(WX_ERR_INVALID, "audio shorter than one STFT window");
@@ -509,6 +530,7 @@ int wx_mel_stage1(wx_engine* e, const float* d_pcm, int64_t pcm_offset, int64_t 
 
 int wx_mel_stage2(wx_engine* e, float* d_logmel, int64_t ld, int64_t n_frames, const float* d_max, void* stream) {
     if (!e || !e->finalized) return fail(WX_ERR_STATE, "engine not finalized");
+    DeviceScope dev_scope(e);
     if (!d_logmel || !d_max || n_frames < 0 || ld < n_frames) return fail(WX_ERR_INVALID, "bad mel arguments");
     WX_TRY(launch_mel_stage2(d_logmel, ld, e->cfg.n_mels, n_frames, d_max, (hipStream_t)stream));
     return WX_OK;
@@ -533,6 +555,7 @@ static int encoder_attention(wx_engine* e, int B, hipStream_t st) {
 int wx_encode(wx_engine* e, const float* d_mel, int64_t win_stride, int64_t row_stride, int64_t n_valid_frames, int32_t B,
               void* stream) {
     if (!e || !e->finalized) return fail(WX_ERR_STATE, "engine not finalized");
+    DeviceScope dev_scope(e);
     if (!d_mel || B <= 0 || B > e->cfg.max_batch || win_stride <= 0 || row_stride <= 0)
         return fail(WX_ERR_INVALID, "bad encode arguments (B must be 1..max_batch)");
     hipStream_t st = (hipStream_t)stream;
@@ -601,6 +624,7 @@ int wx_encode(wx_engine* e, const float* d_mel, int64_t win_stride, int64_t row_
 
 int wx_get_encoder_output(wx_engine* e, int32_t B, float* d_out, void* stream) {
     if (!e || !e->finalized) return fail(WX_ERR_STATE, "engine not finalized");
+    DeviceScope dev_scope(e);
     if (!d_out || B <= 0 || B > e->encoded_B) return fail(WX_ERR_INVALID, "no encoder output for that batch");
     WX_TRY(launch_to_f32(e->enc_out, e->dt, d_out, (int64_t)B * e->T * e->d, (hipStream_t)stream));
     return WX_OK;
@@ -822,6 +846,7 @@ static int decode_rows_impl(wx_engine* e, int32_t B, const int32_t* h_rows, cons
                             const wx_decode_opts* opts, float temperature, uint32_t seed, int32_t* d_tokens, int32_t* d_n_tokens,
                             float* d_sum_logprob, float* d_no_speech_prob, int32_t* h_steps, void* stream) {
     if (!e || !e->finalized) return fail(WX_ERR_STATE, "engine not finalized");
+    DeviceScope dev_scope(e);
     if (!h_rows || !h_np || !h_sot || !opts || !d_tokens || !d_n_tokens || !d_sum_logprob || !d_no_speech_prob) return fail(WX_ERR_INVALID, "null argument");
     if (B <= 0 || B > e->encoded_B) return fail(WX_ERR_INVALID, "decode batch exceeds the last wx_encode batch");
     if (!(temperature >= 0.f)) return fail(WX_ERR_INVALID, "temperature must be >= 0");
@@ -973,6 +998,7 @@ int wx_decode_beam(wx_engine* e, int32_t B, int32_t beam_size, float patience, c
                    int32_t* d_fin_tokens, float* d_fin_sum_logprob, int32_t* d_fin_count, int32_t* d_beam_tokens,
                    float* d_beam_sum_logprob, float* d_no_speech_prob, int32_t* h_steps, void* stream) {
     if (!e || !e->finalized) return fail(WX_ERR_STATE, "engine not finalized");
+    DeviceScope dev_scope(e);
     if (!h_prompt || !opts || !d_fin_tokens || !d_fin_sum_logprob || !d_fin_count || !d_beam_tokens || !d_beam_sum_logprob || !d_no_speech_prob)
         return fail(WX_ERR_INVALID, "null argument");
     const wx_config& c = e->cfg;
@@ -1076,6 +1102,7 @@ int wx_get_profile(wx_engine* e, double* total_ms, int64_t* launches) {
 
 int wx_decoder_logits(wx_engine* e, int32_t B, const int32_t* d_tokens, int32_t n, float* d_logits, void* stream) {
     if (!e || !e->finalized) return fail(WX_ERR_STATE, "engine not finalized");
+    DeviceScope dev_scope(e);
     if (!d_tokens || !d_logits || n <= 0 || n > e->cfg.n_text_ctx) return fail(WX_ERR_INVALID, "bad argument");
     if (B <= 0 || B > e->encoded_B) return fail(WX_ERR_INVALID, "batch exceeds the last wx_encode batch");
     const wx_config& c = e->cfg;
