@@ -418,8 +418,10 @@ __device__ __forceinline__ float wave_max(float x) {
 
 // online (max, sum exp) pair
 struct MS { float m, s; };
+// __expf (v_exp_f32, ~2 ulp) instead of expf: the sum feeds one logf per row, and the ~15-instruction expf made the
+// sampler ALU-bound (one call per vocabulary entry)
 __device__ __forceinline__ void ms_add(MS& a, float v) {
-    if (v > a.m) { a.s = a.s * expf(a.m - v) + 1.f; a.m = v; } else a.s += expf(v - a.m);
+    if (v > a.m) { a.s = a.s * __expf(a.m - v) + 1.f; a.m = v; } else a.s += __expf(v - a.m);
 }
 __device__ __forceinline__ MS ms_merge(MS a, MS b) {
     if (b.m == -INFINITY) return a;
