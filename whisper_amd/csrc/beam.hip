@@ -47,7 +47,7 @@ struct TopList {
 
 struct MS2 { float m, s; };
 __device__ __forceinline__ void ms2_add(MS2& a, float v) {
-    if (v > a.m) { a.s = a.s * expf(a.m - v) + 1.f; a.m = v; } else a.s += expf(v - a.m);
+    if (v > a.m) { a.s = a.s * __expf(a.m - v) + 1.f; a.m = v; } else a.s += __expf(v - a.m);
 }
 __device__ __forceinline__ MS2 ms2_merge(MS2 a, MS2 b) {
     if (b.m == -INFINITY) return a;
