@@ -592,10 +592,12 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
             if (g.K % TB_BK != 0) return -1;
             static const bool no256 = getenv("WX_NO_TILE256") != nullptr;
             if (!no256 && g.M >= 4096 && g.N % TL_BN == 0 && g.K >= 2 * TL_BK) {
-                static bool attr_set = false;
-                if (!attr_set) {
+                static bool attr_set[64] = {};                    // the attribute is per device
+                int dev = 0;
+                if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -2;
+                if (!attr_set[dev]) {
                     if (hipFuncSetAttribute((const void*)gemm_bf16_tile256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS) != hipSuccess) return -2;
-                    attr_set = true;
+                    attr_set[dev] = true;
                 }
                 const int tiles = ((g.M + TL_BM - 1) / TL_BM) * (g.N / TL_BN);
                 hipLaunchKernelGGL(gemm_bf16_tile256_kernel, dim3(tiles), dim3(512), TL_LDS, st, g);
