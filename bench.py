@@ -194,7 +194,8 @@ def main():
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if prof_n else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_cross_attn_pmc.json")
-        if os.path.exists(pmc):
+        # the committed PMC pass is of the default workload's launch; other shapes report no traffic figure
+        if os.path.exists(pmc) and (args.model, B, args.precision) == ("large-v3", 64, "bf16"):
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
