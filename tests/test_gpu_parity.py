@@ -423,6 +423,35 @@ def test_temperature_fallback_sampling(models):
     assert all(lp < 0 for lp in a["sum_logprobs"])
 
 
+@pytest.mark.parametrize("d", [512, 768, 1024])
+def test_logits_gemm_wide_kernel_shapes_bf16(d):
+    """The vocabulary projection (N = 51865, whole K per workgroup) runs on the persistent wide-N decode GEMM; K = 384 and
+    1280 are covered by the tiny / large-v3 tests, the other model widths here with one-layer models: 80 rows (five row
+    tiles) against the fp32 oracle, and bit-identical rows when the same windows are decoded two at a time (one row tile)."""
+    import dataclasses
+    from whisper_amd.engine import WhisperEngine
+    dims = dataclasses.replace(ck.dims_for("base"), n_audio_state=d, n_audio_head=d // 64, n_audio_layer=1,
+                               n_text_state=d, n_text_head=d // 64, n_text_layer=1)
+    sd = ck.synthetic_state_dict(dims, seed=0, attn_gain=1.0)
+    eng = WhisperEngine(dims, sd, precision="bf16", max_batch=80)
+    try:
+        om = wo.OracleWhisper(dims, sd)
+        mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(s), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000] for s in (0, 1)])
+        tok = eng.tok
+        toks = torch.tensor([[tok.sot, tok.lang(0), tok.transcribe, tok.no_timestamps, 100, 2000],
+                             [tok.sot, tok.lang(3), tok.transcribe, tok.no_timestamps, 7, 50000]])
+        with torch.no_grad():
+            ref = om.logits(toks, om.encode(mels))
+        eng.encode_windows(mels.repeat(40, 1, 1))
+        big = eng.decoder_logits(toks.repeat(40, 1)).cpu()
+        check_close(big[:2], ref, "bf16", sharp=False)
+        assert torch.equal(big[78:80], big[:2])
+        eng.encode_windows(mels)
+        assert torch.equal(eng.decoder_logits(toks).cpu(), big[:2])
+    finally:
+        eng.close()
+
+
 def test_large_v3_full_size_bf16():
     """BASELINE configs[2] dimensions (large-v3: d 1280, 20 heads, 32 + 32 layers, 128 mel bins, vocab 51866), bf16: encoder
     output and teacher-forced logits of one window against the fp32 oracle, and the size-independent properties of the

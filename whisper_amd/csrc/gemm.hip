@@ -464,6 +464,135 @@ static bool launch_decode_mt(const GemmArgs& g, int cks, int nch, int blocks, hi
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// bf16 decode GEMM, wide N, whole K per workgroup (the logits: N = vocabulary, 133 MB of weights at d = 1280).
+// The kernel above gives such a shape 812 workgroups of one round each, one resident per CU (its LDS): 3.2 rounds with
+// every stream drained and refilled in between.  Here the grid is one workgroup of 8 waves per CU and stays: the 16-column
+// units are dealt out evenly, a wave takes one unit per round, and its weight stream is a ring of two K chunks (2 x CKS KiB
+// per wave in flight) that runs on across rounds -- the refill of a chunk register set is issued right after its MFMAs, for
+// the same unit or the next one.  The activation chunk for step s + 1 is written to the other LDS buffer after the MFMAs of
+// step s (it was fetched a step earlier, ahead of the weight refills, so its wait never covers an HBM load).  k order and
+// MFMA shape are those of the kernel above: results are bit-identical.  NCH must be even (the ring index is static).
+// Epilogue: plain fp32 row-major store only (no loads, no branches between the rounds).
+// ---------------------------------------------------------------------------------------------------------
+template <int MT, int CKS, int NCH>
+__global__ __launch_bounds__(512) void gemm_bf16_decode_wide_kernel(GemmArgs g) {
+    static_assert(NCH % 2 == 0, "ring of two chunk buffers");
+    constexpr int NW = 8;
+    constexpr int ROWB = CKS * 64 + 32, CK = CKS * 32, CPR = CKS * 4;
+    constexpr int PIECES = MT * 16 * CPR, PPT = (PIECES + 511) / 512, BUF = MT * 16 * ROWB;
+    __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int gq = lane >> 4, r = lane & 15;
+    const int nunits = (g.N + 15) / 16;
+    const int u_begin = (int)((int64_t)blockIdx.x * nunits / gridDim.x), u_end = (int)((int64_t)(blockIdx.x + 1) * nunits / gridDim.x);
+    const int rounds = (u_end - u_begin + NW - 1) / NW;          // >= 1: the launcher keeps gridDim.x <= nunits
+
+    const bf16* xsrc[PPT];
+    int xdst[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        int p = tid + j * 512; if (p > PIECES - 1) p = PIECES - 1;     // duplicates write identical bytes
+        int row = p / CPR; const int c = p % CPR;
+        xdst[j] = row * ROWB + c * 16;
+        if (row > g.M - 1) row = g.M - 1;
+        xsrc[j] = reinterpret_cast<const bf16*>(g.A) + (int64_t)row * g.lda + c * 8;
+    }
+    auto unit_of = [&](int rd) { int u = u_begin + rd * NW + wid; return u > u_end - 1 ? u_end - 1 : u; };   // idle waves shadow the last unit
+    auto wptr = [&](int u) {
+        int n = u * 16 + r; if (n > g.N - 1) n = g.N - 1;
+        return reinterpret_cast<const bf16*>(g.W) + (int64_t)n * g.ldw + gq * 8;
+    };
+    bf16x8 xs[PPT], w[2][CKS];
+    const bf16* wp = wptr(unit_of(0));
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) xs[j] = *reinterpret_cast<const bf16x8*>(xsrc[j]);
+#pragma unroll
+    for (int ks = 0; ks < CKS; ++ks) w[0][ks] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + ks * 32));
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) *reinterpret_cast<bf16x8*>(lds + xdst[j]) = xs[j];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) xs[j] = *reinterpret_cast<const bf16x8*>(xsrc[j] + CK);
+    __builtin_amdgcn_sched_barrier(0);      // activations stay ahead of the weights in the load queue (waits retire in order)
+#pragma unroll
+    for (int ks = 0; ks < CKS; ++ks) w[1][ks] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + CK + ks * 32));
+    __syncthreads();
+
+    // Only the last round can have idle waves (units are dealt 8 per round): they skip weights and MFMAs but keep staging
+    // activations and meeting the barriers.  act = this wave has a unit in this round, act_nxt = in the next one.
+    auto round = [&](auto last_tag, int rd, const bf16* wp_cur, const bf16* wp_nxt, bool act, bool act_nxt) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        f32x4 acc[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const char* buf = lds + (c & 1) * BUF;      // (the conditions on c below fold once the chunk loop is unrolled)
+            if (!LAST || act) {
+#pragma unroll
+                for (int ks = 0; ks < CKS; ++ks) {
+                    bf16x8 xf[MT];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(buf + (i * 16 + r) * ROWB + ks * 64 + gq * 16);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c & 1][ks], xf[i], acc[i], 0, 0, 0);
+                }
+            }
+            if (!(LAST && c == NCH - 1)) {         // activations of the next step: fetched a step ago
+                char* nb = lds + ((c + 1) & 1) * BUF;
+#pragma unroll
+                for (int j = 0; j < PPT; ++j) *reinterpret_cast<bf16x8*>(nb + xdst[j]) = xs[j];
+            }
+            if (!(LAST && c + 2 >= NCH)) {         // fetch for the step after next: activations first, then the ring refill
+#pragma unroll
+                for (int j = 0; j < PPT; ++j) xs[j] = *reinterpret_cast<const bf16x8*>(xsrc[j] + ((c + 2) % NCH) * CK);
+                __builtin_amdgcn_sched_barrier(0);
+                if (c + 2 < NCH) {
+                    if (!LAST || act) {
+#pragma unroll
+                        for (int ks = 0; ks < CKS; ++ks) w[c & 1][ks] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp_cur + (c + 2) * CK + ks * 32));
+                    }
+                } else if (act_nxt) {
+#pragma unroll
+                    for (int ks = 0; ks < CKS; ++ks) w[c & 1][ks] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp_nxt + (c + 2 - NCH) * CK + ks * 32));
+                }
+            }
+            if (!(LAST && c == NCH - 1)) __syncthreads();
+        }
+        if (!LAST || act) {              // plain fp32 row-major store (the launcher admits no other epilogue here)
+            const int n = (u_begin + rd * NW + wid) * 16 + gq * 4;
+            float* out = reinterpret_cast<float*>(g.ep.out);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int m = i * 16 + r;
+                if (m < g.M && n < g.N) *reinterpret_cast<f32x4*>(out + (int64_t)m * g.ep.ldo + n) = acc[i];
+            }
+        }
+    };
+    auto active = [&](int rd) { return u_begin + rd * NW + wid < u_end; };
+    for (int rd = 0; rd + 1 < rounds; ++rd) {
+        const bf16* wn = wptr(unit_of(rd + 1));
+        round(std::false_type{}, rd, wp, wn, true, active(rd + 1));
+        wp = wn;
+    }
+    round(std::true_type{}, rounds - 1, wp, wp, active(rounds - 1), false);
+}
+
+// (CKS, NCH) of the wide kernel for a K; 0 = not covered
+static int decode_wide_cks(int K, int* nch) {
+    for (int cks : {10, 8, 6})
+        for (int n : {4, 2})
+            if (K == cks * 32 * n) { *nch = n; return cks; }
+    return 0;
+}
+template <int MT>
+static bool launch_decode_wide(const GemmArgs& g, int cks, int nch, int blocks, hipStream_t st) {
+#define WX_WIDE(C, N) if (cks == C && nch == N) { hipLaunchKernelGGL((gemm_bf16_decode_wide_kernel<MT, C, N>), dim3(blocks), dim3(512), 0, st, g); return true; }
+    WX_WIDE(10, 4) WX_WIDE(10, 2) WX_WIDE(8, 4) WX_WIDE(8, 2) WX_WIDE(6, 4) WX_WIDE(6, 2)
+#undef WX_WIDE
+    return false;
+}
+
 // k-steps (of 32) per LDS chunk for a K slice of kb; 0 = unsupported slice length
 static int decode_gemm_cks(int kb) {
     if (kb % 320 == 0 && kb / 320 <= 4) return 10;
@@ -577,7 +706,24 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
         const int kb = (g.n_split >= 1 && g.K % g.n_split == 0) ? g.K / g.n_split : 0;
         const int cks = kb ? decode_gemm_cks(kb) : 0;
         if (g.n_split > 1 && (!cks || !g.partial || g.M > DG_MAX_ROWS || g.a_rows_per_batch != 0)) return -1;
-        if (g.M <= DG_MAX_ROWS && g.a_rows_per_batch == 0 && cks) {
+        static const bool no_wide = getenv("WX_NO_WIDE") != nullptr;
+        int wnch = 0;
+        const GemmEpilogue& ep = g.ep;
+        const bool plain_f32 = ep.out && ep.out_dtype == DT_F32 && !ep.bias && !ep.act && !ep.residual && !ep.rowadd && !ep.colscale_period
+                               && ep.mode == 0 && !ep.out_rows_per_batch && ep.ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(ep.out) & 15) == 0;
+        const int wcks = (!no_wide && g.n_split <= 1 && g.N >= 16384 && plain_f32) ? decode_wide_cks(g.K, &wnch) : 0;
+        if (g.M <= DG_MAX_ROWS && g.a_rows_per_batch == 0 && wcks) {
+            const int nunits = (g.N + 15) / 16, blocks = nunits / 8 < 256 ? nunits / 8 : 256;     // one workgroup per CU
+            bool ok;
+            switch ((g.M + 15) / 16) {
+                case 1: ok = launch_decode_wide<1>(g, wcks, wnch, blocks, st); break;
+                case 2: ok = launch_decode_wide<2>(g, wcks, wnch, blocks, st); break;
+                case 3: ok = launch_decode_wide<3>(g, wcks, wnch, blocks, st); break;
+                case 4: ok = launch_decode_wide<4>(g, wcks, wnch, blocks, st); break;
+                default: ok = launch_decode_wide<5>(g, wcks, wnch, blocks, st); break;
+            }
+            if (!ok) return -1;
+        } else if (g.M <= DG_MAX_ROWS && g.a_rows_per_batch == 0 && cks) {
             const int blocks = ((g.N + DG_BN - 1) / DG_BN) * g.n_split, nch = kb / (cks * 32);
             bool ok;
             switch ((g.M + 15) / 16) {
