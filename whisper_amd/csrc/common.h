@@ -58,6 +58,9 @@ struct GemmArgs {
     int64_t lda = 0, a_rows_per_batch = 0, a_batch_stride = 0;
     const void* W = nullptr;
     int64_t ldw = 0;
+    // optional bf16 copy of W in MFMA-fragment order, [N/16][K/32][64 lanes][8]: lane (gq, r) of block (u, kb) holds
+    // W[u*16 + r][kb*32 + gq*8 .. +8], so a wave's 16-B-per-lane load is 1 KiB contiguous.  Read by the wide decode kernel.
+    const void* Wpk = nullptr;
     int M = 0, N = 0, K = 0;
     int in_dtype = DT_F32;              // dtype of A and W
     // bf16, M <= DG_MAX_ROWS only: split K over n_split workgroups; raw fp32 partial tiles go to partial[split][M][N] and the
@@ -68,6 +71,8 @@ struct GemmArgs {
 };
 // Returns 0 or a negative wx_status. Chooses the kernel from (dtype, M).
 int launch_gemm(const GemmArgs& g, hipStream_t st);
+// bf16 W [N][K] (row stride ldw) -> the fragment order GemmArgs::Wpk describes; N % 16 == 0, K % 32 == 0
+int launch_pack_gemm_weight(const void* W, int64_t ldw, int N, int K, void* out, hipStream_t st);
 // K-split factor that fills the chip for a bf16 decode GEMM (M <= DG_MAX_ROWS) whose consumer can add partial tiles; 1 = none.
 int decode_gemm_split(int N, int K);
 

@@ -32,7 +32,8 @@ namespace {
 
 struct HostTensor { std::vector<float> data; std::vector<int64_t> shape; };
 
-struct AttnW { void* wqkv = nullptr; float* bqkv = nullptr; void* wo = nullptr; float* bo = nullptr; };
+struct AttnW { void* wqkv = nullptr; float* bqkv = nullptr; void* wo = nullptr; float* bo = nullptr;
+               void *wqkv_pk = nullptr, *wo_pk = nullptr; };   // _pk: decoder only, MFMA-fragment order (GemmArgs::Wpk)
 struct LayerW {
     float *ln1_g = nullptr, *ln1_b = nullptr;
     AttnW self;
@@ -42,6 +43,7 @@ struct LayerW {
     void* xo = nullptr; float* xbo = nullptr;
     float *ln2_g = nullptr, *ln2_b = nullptr;
     void* w1 = nullptr; float* b1 = nullptr; void* w2 = nullptr; float* b2 = nullptr;
+    void *w1_pk = nullptr, *w2_pk = nullptr, *xq_pk = nullptr, *xo_pk = nullptr;
 };
 
 }  // namespace
@@ -65,7 +67,7 @@ struct wx_engine {
     void *conv1_w = nullptr, *conv2_w = nullptr; float *conv1_b = nullptr, *conv2_b = nullptr, *enc_pos = nullptr;
     std::vector<LayerW> enc, dec;
     float *lnpost_g = nullptr, *lnpost_b = nullptr, *declnf_g = nullptr, *declnf_b = nullptr;
-    void *tok_emb = nullptr, *dec_pos = nullptr;
+    void *tok_emb = nullptr, *dec_pos = nullptr, *tok_emb_pk = nullptr;   // _pk: MFMA-fragment order (GemmArgs::Wpk)
     MelTables mel{};
     uint8_t* suppress = nullptr;
 
@@ -136,6 +138,20 @@ int upload_w(wx_engine* e, const float* h, size_t n, void** out) {
     (void)hipFree(tmp);
     if (r1 != hipSuccess || r2 != hipSuccess) return fail(WX_ERR_HIP, "weight upload failed");
     if (r) return r;
+    *out = p;
+    return 0;
+}
+
+// second copy of a decode-GEMM weight in the order its MFMA fragments are loaded (bf16 engines; no-op otherwise)
+int pack_w(wx_engine* e, const void* w, int N, int K, void** out) {
+    static const bool no_pack = getenv("WX_NO_PACK") != nullptr;
+    *out = nullptr;
+    if (e->dt != DT_BF16 || no_pack || N % 16 || K % 32) return 0;
+    void* p = nullptr;
+    int r = dev_alloc(e, &p, (size_t)N * K * 2, true);
+    if (r) return r;
+    if (launch_pack_gemm_weight(w, K, N, K, p, nullptr)) return fail(WX_ERR_INVALID, "weight repack refused");
+    HIP_TRY(hipDeviceSynchronize());
     *out = p;
     return 0;
 }
@@ -371,6 +387,9 @@ int wx_finalize(wx_engine* e) {
         }
         if ((r = build_ln(e, p + ".mlp_ln", d, &L.ln2_g, &L.ln2_b))) return r;
         if ((r = build_mlp(e, p, d, L))) return r;
+        if ((r = pack_w(e, L.self.wqkv, 3 * d, d, &L.self.wqkv_pk)) || (r = pack_w(e, L.self.wo, d, d, &L.self.wo_pk)) ||
+            (r = pack_w(e, L.xq, d, d, &L.xq_pk)) || (r = pack_w(e, L.xo, d, d, &L.xo_pk)) ||
+            (r = pack_w(e, L.w1, 4 * d, d, &L.w1_pk)) || (r = pack_w(e, L.w2, d, 4 * d, &L.w2_pk))) return r;
     }
     if ((r = build_ln(e, "decoder.ln", d, &e->declnf_g, &e->declnf_b))) return r;
     {
@@ -380,6 +399,7 @@ int wx_finalize(wx_engine* e) {
         std::vector<float> padded((size_t)e->vocab_pad * d, 0.f);
         memcpy(padded.data(), te->data.data(), te->data.size() * 4);
         if ((r = upload_w(e, padded.data(), padded.size(), &e->tok_emb))) return r;
+        if ((r = pack_w(e, e->tok_emb, e->vocab_pad, d, &e->tok_emb_pk))) return r;   // for the vocabulary projection
         if ((r = upload_w(e, pe->data.data(), pe->data.size(), &e->dec_pos))) return r;
     }
     e->staged.clear();
@@ -753,8 +773,9 @@ static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, floa
     const int s_dd = o_dd ? o_dd : decode_gemm_split(d, d), s_fc2 = o_fc2 ? o_fc2 : decode_gemm_split(d, 4 * d),
               s_qkv = o_qkv ? o_qkv : decode_gemm_split(3 * d, d), s_fc1 = o_fc1 ? o_fc1 : decode_gemm_split(4 * d, d);
     int pend_split = 0; const float* pend_bias = nullptr;       // residual update not yet folded into dx
-    auto split_gemm = [&](const void* A, int64_t lda, const void* W, int K, int S) {
+    auto split_gemm = [&](const void* A, int64_t lda, const void* W, const void* Wpk, int K, int S) {
         GemmArgs g = gemm_basic(e, A, lda, W, B, d, K);
+        g.Wpk = Wpk;
         g.n_split = S; g.partial = gpartial;
         if (S == 1) { g.ep.out = gpartial; g.ep.out_dtype = DT_F32; g.ep.ldo = d; }   // one "partial": same consumer path
         return launch_gemm(g, st);
@@ -764,6 +785,7 @@ static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, floa
         WX_TRY(launch_reduce_layernorm(dx, gpartial, pend_split, pend_bias, L.ln1_g, L.ln1_b, dxn, dtp, B, d, st));
         {   // fused q|k|v projection, split K: the self-attention kernel adds the partial tiles, bias and scale itself
             GemmArgs g = gemm_basic(e, dxn, d, L.self.wqkv, B, 3 * d, d);
+            g.Wpk = L.self.wqkv_pk;
             g.n_split = s_qkv; g.partial = gpartial;
             if (s_qkv == 1) { g.ep.out = gpartial; g.ep.out_dtype = DT_F32; g.ep.ldo = 3 * d; }
             WX_TRY(launch_gemm(g, st));
@@ -777,9 +799,9 @@ static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, floa
             if (G > 1) WX_TRY(launch_kv_append(a, st));
             WX_TRY(launch_attn_decode(a, st));
         }
-        WX_TRY(split_gemm(datt, d, L.self.wo, d, s_dd));
+        WX_TRY(split_gemm(datt, d, L.self.wo, L.self.wo_pk, d, s_dd));
         WX_TRY(launch_reduce_layernorm(dx, gpartial, s_dd, L.self.bo, L.lnx_g, L.lnx_b, dxn, dtp, B, d, st));
-        WX_TRY(split_gemm(dxn, d, L.xq, d, s_dd));
+        WX_TRY(split_gemm(dxn, d, L.xq, L.xq_pk, d, s_dd));
         {
             AttnArgs a;
             a.dt = dtp; a.q_partial = gpartial; a.q_bias = L.xbq; a.q_nsplit = s_dd; a.q_scale = e->qk_scale; a.q_sb = d; a.n_q = 1;
@@ -791,22 +813,24 @@ static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, floa
             WX_TRY(launch_attn_decode(a, st));
             if (prof) { HIP_TRY(hipEventRecord(e->prof_events[e->prof_used + 1], st)); e->prof_used += 2; }
         }
-        WX_TRY(split_gemm(datt, d, L.xo, d, s_dd));
+        WX_TRY(split_gemm(datt, d, L.xo, L.xo_pk, d, s_dd));
         WX_TRY(launch_reduce_layernorm(dx, gpartial, s_dd, L.xbo, L.ln2_g, L.ln2_b, dxn, dtp, B, d, st));
         {
             GemmArgs g = gemm_basic(e, dxn, d, L.w1, B, 4 * d, d);
+            g.Wpk = L.w1_pk;
             if (s_fc1 > 1) { g.n_split = s_fc1; g.partial = gpartial; }
             else { g.ep.bias = L.b1; g.ep.act = 1; g.ep.out = dhid; g.ep.out_dtype = dtp; g.ep.ldo = 4 * d; }
             WX_TRY(launch_gemm(g, st));
             if (s_fc1 > 1) WX_TRY(launch_reduce_bias_gelu(gpartial, s_fc1, L.b1, dhid, B, 4 * d, st));
         }
-        WX_TRY(split_gemm(dhid, 4 * d, L.w2, 4 * d, s_fc2));
+        WX_TRY(split_gemm(dhid, 4 * d, L.w2, L.w2_pk, 4 * d, s_fc2));
         pend_split = s_fc2; pend_bias = L.b2;
     }
     if (!want_logits) return 0;      // prompt pass with no row at its SOT position: the residual stream is not needed again
     WX_TRY(launch_reduce_layernorm(dx, gpartial, pend_split, pend_bias, e->declnf_g, e->declnf_b, dxn, dtp, B, d, st));
     {
         GemmArgs g = gemm_basic(e, dxn, d, e->tok_emb, B, e->vocab_pad, d);
+        g.Wpk = e->tok_emb_pk;
         g.ep.out = e->logits + (size_t)b0 * e->vocab_pad; g.ep.out_dtype = DT_F32; g.ep.ldo = e->vocab_pad;
         WX_TRY(launch_gemm(g, st));
     }

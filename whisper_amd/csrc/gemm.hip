@@ -365,8 +365,9 @@ constexpr int DG_BN = 64;
 
 // NCH = chunks per K slice (compile time, <= 4): the chunk loop is fully unrolled, EVERY weight load of the slice is in
 // flight before the first MFMA (NCH*CKS KiB per wave), and activation chunks are fetched two ahead.
-template <int MT, int CKS, int NCH>
+template <int MT, int CKS, int NCH, bool PACKED>
 __global__ __launch_bounds__(256) void gemm_bf16_decode_kernel(GemmArgs g) {
+    constexpr int KS = PACKED ? 512 : 32;        // elements between consecutive k-steps of a lane's weight stream (GemmArgs::Wpk)
     constexpr int ROWB = CKS * 64 + 32;           // padded LDS row (bytes)
     constexpr int CK = CKS * 32;                  // k per chunk
     constexpr int CPR = CKS * 4;                  // 16-B pieces per activation row per chunk
@@ -382,7 +383,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_decode_kernel(GemmArgs g) {
     const int kbeg = split * (NCH * CK);
 
     int n = n0 + r; if (n > g.N - 1) n = g.N - 1;
-    const bf16* wp = reinterpret_cast<const bf16*>(g.W) + (int64_t)n * g.ldw + kbeg + gq * 8;
+    int u = n0 / 16; if (u > g.N / 16 - 1) u = g.N / 16 - 1;     // (waves past a ragged last tile shadow the last unit, as n does)
+    const bf16* wp = PACKED ? reinterpret_cast<const bf16*>(g.Wpk) + ((int64_t)u * (g.K / 32) + kbeg / 32) * 512 + lane * 8
+                            : reinterpret_cast<const bf16*>(g.W) + (int64_t)n * g.ldw + kbeg + gq * 8;
     const bf16* xsrc[PPT];
     int xdst[PPT];
 #pragma unroll
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_decode_kernel(GemmArgs g) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
-        for (int ks = 0; ks < CKS; ++ks) w[c][ks] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + c * CK + ks * 32));
+        for (int ks = 0; ks < CKS; ++ks) w[c][ks] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + (c * CKS + ks) * KS));
     f32x4 acc[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -446,13 +449,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_decode_kernel(GemmArgs g) {
 
 template <int MT, int CKS>
 static bool launch_decode_nch(const GemmArgs& g, int nch, int blocks, hipStream_t st) {
+#define WX_DG(N) case N: if (g.Wpk) hipLaunchKernelGGL((gemm_bf16_decode_kernel<MT, CKS, N, true>), dim3(blocks), dim3(256), 0, st, g); \
+                         else hipLaunchKernelGGL((gemm_bf16_decode_kernel<MT, CKS, N, false>), dim3(blocks), dim3(256), 0, st, g); return true;
     switch (nch) {
-        case 1: hipLaunchKernelGGL((gemm_bf16_decode_kernel<MT, CKS, 1>), dim3(blocks), dim3(256), 0, st, g); return true;
-        case 2: hipLaunchKernelGGL((gemm_bf16_decode_kernel<MT, CKS, 2>), dim3(blocks), dim3(256), 0, st, g); return true;
-        case 3: hipLaunchKernelGGL((gemm_bf16_decode_kernel<MT, CKS, 3>), dim3(blocks), dim3(256), 0, st, g); return true;
-        case 4: hipLaunchKernelGGL((gemm_bf16_decode_kernel<MT, CKS, 4>), dim3(blocks), dim3(256), 0, st, g); return true;
+        WX_DG(1) WX_DG(2) WX_DG(3) WX_DG(4)
         default: return false;
     }
+#undef WX_DG
 }
 template <int MT>
 static bool launch_decode_mt(const GemmArgs& g, int cks, int nch, int blocks, hipStream_t st) {
@@ -475,12 +478,11 @@ static bool launch_decode_mt(const GemmArgs& g, int cks, int nch, int blocks, hi
 // MFMA shape are those of the kernel above: results are bit-identical.  NCH must be even (the ring index is static).
 // Epilogue: plain fp32 row-major store only (no loads, no branches between the rounds).
 // ---------------------------------------------------------------------------------------------------------
-template <int MT, int CKS, int NCH>
-__global__ __launch_bounds__(512) void gemm_bf16_decode_wide_kernel(GemmArgs g) {
+template <int MT, int CKS, int NCH, int NW, bool PACKED>
+__global__ __launch_bounds__(NW * 64) void gemm_bf16_decode_wide_kernel(GemmArgs g) {
     static_assert(NCH % 2 == 0, "ring of two chunk buffers");
-    constexpr int NW = 8;
     constexpr int ROWB = CKS * 64 + 32, CK = CKS * 32, CPR = CKS * 4;
-    constexpr int PIECES = MT * 16 * CPR, PPT = (PIECES + 511) / 512, BUF = MT * 16 * ROWB;
+    constexpr int PIECES = MT * 16 * CPR, PPT = (PIECES + NW * 64 - 1) / (NW * 64), BUF = MT * 16 * ROWB;
     __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int gq = lane >> 4, r = lane & 15;
@@ -492,14 +494,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_decode_wide_kernel(GemmArgs g) 
     int xdst[PPT];
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
-        int p = tid + j * 512; if (p > PIECES - 1) p = PIECES - 1;     // duplicates write identical bytes
+        int p = tid + j * NW * 64; if (p > PIECES - 1) p = PIECES - 1;     // duplicates write identical bytes
         int row = p / CPR; const int c = p % CPR;
         xdst[j] = row * ROWB + c * 16;
         if (row > g.M - 1) row = g.M - 1;
         xsrc[j] = reinterpret_cast<const bf16*>(g.A) + (int64_t)row * g.lda + c * 8;
     }
     auto unit_of = [&](int rd) { int u = u_begin + rd * NW + wid; return u > u_end - 1 ? u_end - 1 : u; };   // idle waves shadow the last unit
+    constexpr int KS = PACKED ? 512 : 32;          // elements between consecutive k-steps of a lane's weight stream
     auto wptr = [&](int u) {
+        if constexpr (PACKED) return reinterpret_cast<const bf16*>(g.Wpk) + (int64_t)u * (g.K / 32) * 512 + lane * 8;
         int n = u * 16 + r; if (n > g.N - 1) n = g.N - 1;
         return reinterpret_cast<const bf16*>(g.W) + (int64_t)n * g.ldw + gq * 8;
     };
@@ -507,15 +511,20 @@ __global__ __launch_bounds__(512) void gemm_bf16_decode_wide_kernel(GemmArgs g) 
     const bf16* wp = wptr(unit_of(0));
 #pragma unroll
     for (int j = 0; j < PPT; ++j) xs[j] = *reinterpret_cast<const bf16x8*>(xsrc[j]);
+    const bool act0 = u_begin + wid < u_end;          // false only for the spare waves of a single-round workgroup
+    if (act0) {
 #pragma unroll
-    for (int ks = 0; ks < CKS; ++ks) w[0][ks] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + ks * 32));
+        for (int ks = 0; ks < CKS; ++ks) w[0][ks] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + ks * KS));
+    }
 #pragma unroll
     for (int j = 0; j < PPT; ++j) *reinterpret_cast<bf16x8*>(lds + xdst[j]) = xs[j];
 #pragma unroll
     for (int j = 0; j < PPT; ++j) xs[j] = *reinterpret_cast<const bf16x8*>(xsrc[j] + CK);
     __builtin_amdgcn_sched_barrier(0);      // activations stay ahead of the weights in the load queue (waits retire in order)
+    if (act0) {
 #pragma unroll
-    for (int ks = 0; ks < CKS; ++ks) w[1][ks] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + CK + ks * 32));
+        for (int ks = 0; ks < CKS; ++ks) w[1][ks] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + (CKS + ks) * KS));
+    }
     __syncthreads();
 
     // Only the last round can have idle waves (units are dealt 8 per round): they skip weights and MFMAs but keep staging
@@ -550,11 +559,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_decode_wide_kernel(GemmArgs g) 
                 if (c + 2 < NCH) {
                     if (!LAST || act) {
 #pragma unroll
-                        for (int ks = 0; ks < CKS; ++ks) w[c & 1][ks] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp_cur + (c + 2) * CK + ks * 32));
+                        for (int ks = 0; ks < CKS; ++ks) w[c & 1][ks] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp_cur + ((c + 2) * CKS + ks) * KS));
                     }
                 } else if (act_nxt) {
 #pragma unroll
-                    for (int ks = 0; ks < CKS; ++ks) w[c & 1][ks] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp_nxt + (c + 2 - NCH) * CK + ks * 32));
+                    for (int ks = 0; ks < CKS; ++ks) w[c & 1][ks] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp_nxt + ((c + 2 - NCH) * CKS + ks) * KS));
                 }
             }
             if (!(LAST && c == NCH - 1)) __syncthreads();
@@ -578,17 +587,28 @@ __global__ __launch_bounds__(512) void gemm_bf16_decode_wide_kernel(GemmArgs g) 
     round(std::true_type{}, rounds - 1, wp, wp, active(rounds - 1), false);
 }
 
-// (CKS, NCH) of the wide kernel for a K; 0 = not covered
-static int decode_wide_cks(int K, int* nch) {
+// (CKS, NCH) of the wide kernel for a K; 0 = not covered.  wide16: 16 waves per workgroup (128 registers per wave: chunks of
+// at most 6 k-steps), one round of units per workgroup at the vocabulary's width instead of two.
+static int decode_wide_cks(int K, bool wide16, int* nch) {
+    if (wide16) {
+        for (int cks : {6, 5, 4})
+            for (int n : {8, 4, 2})
+                if (K == cks * 32 * n) { *nch = n; return cks; }
+        return 0;
+    }
     for (int cks : {10, 8, 6})
         for (int n : {4, 2})
             if (K == cks * 32 * n) { *nch = n; return cks; }
     return 0;
 }
 template <int MT>
-static bool launch_decode_wide(const GemmArgs& g, int cks, int nch, int blocks, hipStream_t st) {
-#define WX_WIDE(C, N) if (cks == C && nch == N) { hipLaunchKernelGGL((gemm_bf16_decode_wide_kernel<MT, C, N>), dim3(blocks), dim3(512), 0, st, g); return true; }
-    WX_WIDE(10, 4) WX_WIDE(10, 2) WX_WIDE(8, 4) WX_WIDE(8, 2) WX_WIDE(6, 4) WX_WIDE(6, 2)
+static bool launch_decode_wide(const GemmArgs& g, int cks, int nch, bool wide16, int blocks, hipStream_t st) {
+#define WX_WIDE(C, N, W) if (cks == C && nch == N && wide16 == (W == 16)) { \
+        if (g.Wpk) hipLaunchKernelGGL((gemm_bf16_decode_wide_kernel<MT, C, N, W, true>), dim3(blocks), dim3(W * 64), 0, st, g); \
+        else hipLaunchKernelGGL((gemm_bf16_decode_wide_kernel<MT, C, N, W, false>), dim3(blocks), dim3(W * 64), 0, st, g); \
+        return true; }
+    WX_WIDE(10, 4, 8) WX_WIDE(10, 2, 8) WX_WIDE(8, 4, 8) WX_WIDE(8, 2, 8) WX_WIDE(6, 4, 8) WX_WIDE(6, 2, 8)
+    WX_WIDE(5, 8, 16) WX_WIDE(4, 8, 16) WX_WIDE(6, 4, 16) WX_WIDE(4, 4, 16) WX_WIDE(6, 2, 16)
 #undef WX_WIDE
     return false;
 }
@@ -693,6 +713,25 @@ __global__ __launch_bounds__(256) void gemm_f32_tile_kernel(GemmArgs g) {
             epilogue_store4(g.ep, m0 + wm * WM + i * 16 + r, n0 + wn * WN + j * 16 + gq * 4, acc[j][i], g.M, g.N);
 }
 
+// W [N][K] bf16 row-major -> MFMA-fragment order [N/16][K/32][64][8] (GemmArgs::Wpk); N % 16 == 0, K % 32 == 0
+__global__ void pack_gemm_weight_kernel(const bf16* __restrict__ W, int64_t ldw, int K, bf16* __restrict__ out, int64_t pieces) {
+    const int kb_n = K / 32;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < pieces; p += (int64_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(p & 63);
+        const int64_t blk = p >> 6;
+        const int kb = (int)(blk % kb_n);
+        const int64_t u = blk / kb_n;
+        *reinterpret_cast<bf16x8*>(out + p * 8) = *reinterpret_cast<const bf16x8*>(W + (u * 16 + (lane & 15)) * ldw + kb * 32 + (lane >> 4) * 8);
+    }
+}
+int launch_pack_gemm_weight(const void* W, int64_t ldw, int N, int K, void* out, hipStream_t st) {
+    if (!W || !out || N <= 0 || K <= 0 || N % 16 || K % 32 || ldw % 8) return -1;
+    if ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(out)) & 15) return -1;
+    const int64_t pieces = (int64_t)N * K / 8;
+    hipLaunchKernelGGL(pack_gemm_weight_kernel, dim3(2048), dim3(256), 0, st, reinterpret_cast<const bf16*>(W), ldw, K, reinterpret_cast<bf16*>(out), pieces);
+    return 0;
+}
+
 int launch_gemm(const GemmArgs& g, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return -1;
     if (g.ep.rowadd && g.ep.residual) return -1;
@@ -711,16 +750,18 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
         const GemmEpilogue& ep = g.ep;
         const bool plain_f32 = ep.out && ep.out_dtype == DT_F32 && !ep.bias && !ep.act && !ep.residual && !ep.rowadd && !ep.colscale_period
                                && ep.mode == 0 && !ep.out_rows_per_batch && ep.ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(ep.out) & 15) == 0;
-        const int wcks = (!no_wide && g.n_split <= 1 && g.N >= 16384 && plain_f32) ? decode_wide_cks(g.K, &wnch) : 0;
+        static const bool wide16 = getenv("WX_WIDE16") != nullptr;
+        if (g.Wpk && (g.N % 16 != 0 || (reinterpret_cast<uintptr_t>(g.Wpk) & 15))) return -1;
+        const int wcks = (!no_wide && g.n_split <= 1 && g.N >= 16384 && plain_f32) ? decode_wide_cks(g.K, wide16, &wnch) : 0;
         if (g.M <= DG_MAX_ROWS && g.a_rows_per_batch == 0 && wcks) {
-            const int nunits = (g.N + 15) / 16, blocks = nunits / 8 < 256 ? nunits / 8 : 256;     // one workgroup per CU
+            const int nunits = (g.N + 15) / 16, nw = wide16 ? 16 : 8, blocks = nunits / nw < 256 ? nunits / nw : 256;     // one workgroup per CU
             bool ok;
             switch ((g.M + 15) / 16) {
-                case 1: ok = launch_decode_wide<1>(g, wcks, wnch, blocks, st); break;
-                case 2: ok = launch_decode_wide<2>(g, wcks, wnch, blocks, st); break;
-                case 3: ok = launch_decode_wide<3>(g, wcks, wnch, blocks, st); break;
-                case 4: ok = launch_decode_wide<4>(g, wcks, wnch, blocks, st); break;
-                default: ok = launch_decode_wide<5>(g, wcks, wnch, blocks, st); break;
+                case 1: ok = launch_decode_wide<1>(g, wcks, wnch, wide16, blocks, st); break;
+                case 2: ok = launch_decode_wide<2>(g, wcks, wnch, wide16, blocks, st); break;
+                case 3: ok = launch_decode_wide<3>(g, wcks, wnch, wide16, blocks, st); break;
+                case 4: ok = launch_decode_wide<4>(g, wcks, wnch, wide16, blocks, st); break;
+                default: ok = launch_decode_wide<5>(g, wcks, wnch, wide16, blocks, st); break;
             }
             if (!ok) return -1;
         } else if (g.M <= DG_MAX_ROWS && g.a_rows_per_batch == 0 && cks) {
