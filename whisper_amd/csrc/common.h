@@ -71,6 +71,9 @@ struct GemmArgs {
 };
 // Returns 0 or a negative wx_status. Chooses the kernel from (dtype, M).
 int launch_gemm(const GemmArgs& g, hipStream_t st);
+// bf16 decode GEMM (M <= DG_MAX_ROWS) with K halved inside the workgroup and the full epilogue applied (no partial tiles);
+// needs g.Wpk.  0 = launched, 1 = shape not covered (use the split-K path), < 0 = error.
+int launch_gemm_khalf(const GemmArgs& g, hipStream_t st);
 // bf16 W [N][K] (row stride ldw) -> the fragment order GemmArgs::Wpk describes; N % 16 == 0, K % 32 == 0
 int launch_pack_gemm_weight(const void* W, int64_t ldw, int N, int K, void* out, hipStream_t st);
 // K-split factor that fills the chip for a bf16 decode GEMM (M <= DG_MAX_ROWS) whose consumer can add partial tiles; 1 = none.

@@ -749,7 +749,7 @@ static int decode_step_f32(wx_engine* e, int B, const SamplerArgs* sa, hipStream
 // bf16 sequence (rows [b0, b0 + B) of the batch, B <= DG_MAX_ROWS): the q|k|v projection, the three residual GEMMs of a layer and
 // the cross-attention query projection split K over workgroups and hand raw fp32 partial tiles to their consumer -- the
 // next LayerNorm (reduce + bias + residual + LN in one kernel) or the attention kernel's q/k/v load -- so every weight
-// byte streams once with the whole chip pulling, and no launch is added.  11 launches per layer.
+// byte streams once with the whole chip pulling, and no launch is added.  10 launches per layer (11 where the MLP up projection has to take the split-K path).
 // G > 1 = prompt pass: the B rows are G consecutive forced positions (*d_pos ...) of B / G sequences, row r = sequence r / G,
 // position r % G.  Row-wise kernels do not care; self-attention appends all new k/v rows first and then reads the cache
 // causally per row, cross-attention shares a window's K/V stream among its G rows (the beam-search grouping).
@@ -818,10 +818,21 @@ static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, floa
         {
             GemmArgs g = gemm_basic(e, dxn, d, L.w1, B, 4 * d, d);
             g.Wpk = L.w1_pk;
-            if (s_fc1 > 1) { g.n_split = s_fc1; g.partial = gpartial; }
-            else { g.ep.bias = L.b1; g.ep.act = 1; g.ep.out = dhid; g.ep.out_dtype = dtp; g.ep.ldo = 4 * d; }
-            WX_TRY(launch_gemm(g, st));
-            if (s_fc1 > 1) WX_TRY(launch_reduce_bias_gelu(gpartial, s_fc1, L.b1, dhid, B, 4 * d, st));
+            // K halved inside the workgroup, bias + GELU in the epilogue: no partial tiles, no reduce launch
+            static const bool no_khalf = getenv("WX_NO_KHALF") != nullptr;
+            int fused = 1;
+            if (!no_khalf && !o_fc1 && g.Wpk) {
+                GemmArgs f = g;
+                f.ep.bias = L.b1; f.ep.act = 1; f.ep.out = dhid; f.ep.out_dtype = dtp; f.ep.ldo = 4 * d;
+                fused = launch_gemm_khalf(f, st);
+                if (fused < 0) return fail(WX_ERR_INVALID, "launch_gemm_khalf refused the MLP up projection");
+            }
+            if (fused != 0) {
+                if (s_fc1 > 1) { g.n_split = s_fc1; g.partial = gpartial; }
+                else { g.ep.bias = L.b1; g.ep.act = 1; g.ep.out = dhid; g.ep.out_dtype = dtp; g.ep.ldo = 4 * d; }
+                WX_TRY(launch_gemm(g, st));
+                if (s_fc1 > 1) WX_TRY(launch_reduce_bias_gelu(gpartial, s_fc1, L.b1, dhid, B, 4 * d, st));
+            }
         }
         WX_TRY(split_gemm(dhid, 4 * d, L.w2, L.w2_pk, 4 * d, s_fc2));
         pend_split = s_fc2; pend_bias = L.b2;

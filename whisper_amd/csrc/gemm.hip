@@ -713,6 +713,104 @@ __global__ __launch_bounds__(256) void gemm_f32_tile_kernel(GemmArgs g) {
             epilogue_store4(g.ep, m0 + wm * WM + i * 16 + r, n0 + wn * WN + j * 16 + gq * 4, acc[j][i], g.M, g.N);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// bf16 decode GEMM with the K split INSIDE the workgroup (the MLP up projection): 32 output columns per workgroup, waves
+// (cu, kh) = 16 columns x one half of K each, the two halves added through LDS in a fixed order and the full epilogue
+// (bias, GELU, bf16 store) applied -- the split-K variant above needs a separate reduce + bias + GELU launch for that.
+// Same bytes per CU and per wave in flight as the 64-column x half-K workgroups of the split variant (N / 32 workgroups).
+// Weights come from the fragment-ordered copy (GemmArgs::Wpk) only.  NCH = chunks per K half (1 or 2).
+// ---------------------------------------------------------------------------------------------------------
+template <int MT, int CKS, int NCH>
+__global__ __launch_bounds__(256) void gemm_bf16_decode_khalf_kernel(GemmArgs g) {
+    constexpr int ROWB = CKS * 64 + 32, CK = CKS * 32, CPR = CKS * 4;
+    constexpr int HALF_PIECES = MT * 16 * CPR, PIECES = 2 * HALF_PIECES, PPT = (PIECES + 255) / 256, BUF = MT * 16 * ROWB;
+    static_assert(2 * BUF >= 2 * MT * 64 * 16, "the reduction slab reuses the staging buffers");
+    __shared__ __attribute__((aligned(16))) char lds[2 * BUF];          // [K half][row][ROWB]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int gq = lane >> 4, r = lane & 15;
+    const int cu = wid & 1, kh = wid >> 1;
+    const int n0 = blockIdx.x * 32 + cu * 16;
+    const int khalf = NCH * CK;                                          // launcher: g.K == 2 * khalf, g.N % 32 == 0
+    const bf16* wp = reinterpret_cast<const bf16*>(g.Wpk) + ((int64_t)(n0 / 16) * (g.K / 32) + kh * (khalf / 32)) * 512 + lane * 8;
+    const bf16* xsrc[PPT];
+    int xdst[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        int p = tid + j * 256; if (p > PIECES - 1) p = PIECES - 1;     // duplicates write identical bytes
+        const int h = p / HALF_PIECES, q = p % HALF_PIECES;
+        int row = q / CPR; const int c = q % CPR;
+        xdst[j] = h * BUF + row * ROWB + c * 16;
+        if (row > g.M - 1) row = g.M - 1;
+        xsrc[j] = reinterpret_cast<const bf16*>(g.A) + (int64_t)row * g.lda + h * khalf + c * 8;
+    }
+    bf16x8 xs[PPT], w[NCH][CKS];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) xs[j] = *reinterpret_cast<const bf16x8*>(xsrc[j]);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int ks = 0; ks < CKS; ++ks) w[c][ks] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + (c * CKS + ks) * 512));
+    f32x4 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) *reinterpret_cast<bf16x8*>(lds + xdst[j]) = xs[j];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH) {
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) xs[j] = *reinterpret_cast<const bf16x8*>(xsrc[j] + (c + 1) * CK);
+        }
+        const char* buf = lds + kh * BUF;
+#pragma unroll
+        for (int ks = 0; ks < CKS; ++ks) {
+            bf16x8 xf[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(buf + (i * 16 + r) * ROWB + ks * 64 + gq * 16);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][ks], xf[i], acc[i], 0, 0, 0);
+        }
+        __syncthreads();                                                 // every wave is done with this chunk's activations
+        if (c + 1 < NCH) {
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) *reinterpret_cast<bf16x8*>(lds + xdst[j]) = xs[j];
+            __syncthreads();
+        }
+    }
+    // The two waves of a column unit swap half of their row tiles through LDS and each finishes the epilogue (bias, GELU,
+    // store) of its share: even tiles on the lower-half wave, odd tiles on the upper-half wave, always lower + upper.
+    f32x4* red = reinterpret_cast<f32x4*>(lds) + cu * (MT * 64);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+        if ((i & 1) != kh) red[i * 64 + lane] = acc[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        if ((i & 1) == kh) {
+            const f32x4 o = red[i * 64 + lane];
+            f32x4 v;
+            if (kh == 0) { v[0] = acc[i][0] + o[0]; v[1] = acc[i][1] + o[1]; v[2] = acc[i][2] + o[2]; v[3] = acc[i][3] + o[3]; }
+            else { v[0] = o[0] + acc[i][0]; v[1] = o[1] + acc[i][1]; v[2] = o[2] + acc[i][2]; v[3] = o[3] + acc[i][3]; }
+            epilogue_store4(g.ep, i * 16 + r, n0 + gq * 4, v, g.M, g.N);
+        }
+    }
+}
+
+// 0 = launched, 1 = shape not covered (the caller takes the split-K path), < 0 = error
+int launch_gemm_khalf(const GemmArgs& g, hipStream_t st) {
+    if (g.in_dtype != DT_BF16 || !g.Wpk || g.M <= 0 || g.M > DG_MAX_ROWS || g.a_rows_per_batch != 0 || g.N % 32 || g.K % 64) return 1;
+    if (g.ep.mode != 0 || g.ep.residual || g.ep.rowadd || !g.ep.out) return 1;
+    if ((g.lda * 2) % 16 != 0 || ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.Wpk)) & 15)) return -1;
+    const int khalf = g.K / 2, blocks = g.N / 32, mt = (g.M + 15) / 16;
+#define WX_KH(M_, C, N) if (mt == M_ && khalf == C * 32 * N) { hipLaunchKernelGGL((gemm_bf16_decode_khalf_kernel<M_, C, N>), dim3(blocks), dim3(256), 0, st, g); return 0; }
+#define WX_KH_ALL(M_) WX_KH(M_, 10, 2) WX_KH(M_, 8, 2) WX_KH(M_, 6, 2) WX_KH(M_, 8, 1) WX_KH(M_, 6, 1)
+    WX_KH_ALL(1) WX_KH_ALL(2) WX_KH_ALL(3) WX_KH_ALL(4) WX_KH_ALL(5)
+#undef WX_KH_ALL
+#undef WX_KH
+    return 1;
+}
+
 // W [N][K] bf16 row-major -> MFMA-fragment order [N/16][K/32][64][8] (GemmArgs::Wpk); N % 16 == 0, K % 32 == 0
 __global__ void pack_gemm_weight_kernel(const bf16* __restrict__ W, int64_t ldw, int K, bf16* __restrict__ out, int64_t pieces) {
     const int kb_n = K / 32;
