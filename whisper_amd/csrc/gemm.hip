@@ -587,28 +587,21 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_decode_wide_kernel(GemmArgs
     round(std::true_type{}, rounds - 1, wp, wp, active(rounds - 1), false);
 }
 
-// (CKS, NCH) of the wide kernel for a K; 0 = not covered.  wide16: 16 waves per workgroup (128 registers per wave: chunks of
-// at most 6 k-steps), one round of units per workgroup at the vocabulary's width instead of two.
-static int decode_wide_cks(int K, bool wide16, int* nch) {
-    if (wide16) {
-        for (int cks : {6, 5, 4})
-            for (int n : {8, 4, 2})
-                if (K == cks * 32 * n) { *nch = n; return cks; }
-        return 0;
-    }
+// (CKS, NCH) of the wide kernel for a K; 0 = not covered.  (A 16-wave build with chunks of 5 k-steps, one round of units per
+// workgroup instead of two, measured slower: 32 vs 28 us at d = 1280 -- twice the barriers per byte.)
+static int decode_wide_cks(int K, int* nch) {
     for (int cks : {10, 8, 6})
         for (int n : {4, 2})
             if (K == cks * 32 * n) { *nch = n; return cks; }
     return 0;
 }
 template <int MT>
-static bool launch_decode_wide(const GemmArgs& g, int cks, int nch, bool wide16, int blocks, hipStream_t st) {
-#define WX_WIDE(C, N, W) if (cks == C && nch == N && wide16 == (W == 16)) { \
-        if (g.Wpk) hipLaunchKernelGGL((gemm_bf16_decode_wide_kernel<MT, C, N, W, true>), dim3(blocks), dim3(W * 64), 0, st, g); \
-        else hipLaunchKernelGGL((gemm_bf16_decode_wide_kernel<MT, C, N, W, false>), dim3(blocks), dim3(W * 64), 0, st, g); \
+static bool launch_decode_wide(const GemmArgs& g, int cks, int nch, int blocks, hipStream_t st) {
+#define WX_WIDE(C, N) if (cks == C && nch == N) { \
+        if (g.Wpk) hipLaunchKernelGGL((gemm_bf16_decode_wide_kernel<MT, C, N, 8, true>), dim3(blocks), dim3(512), 0, st, g); \
+        else hipLaunchKernelGGL((gemm_bf16_decode_wide_kernel<MT, C, N, 8, false>), dim3(blocks), dim3(512), 0, st, g); \
         return true; }
-    WX_WIDE(10, 4, 8) WX_WIDE(10, 2, 8) WX_WIDE(8, 4, 8) WX_WIDE(8, 2, 8) WX_WIDE(6, 4, 8) WX_WIDE(6, 2, 8)
-    WX_WIDE(5, 8, 16) WX_WIDE(4, 8, 16) WX_WIDE(6, 4, 16) WX_WIDE(4, 4, 16) WX_WIDE(6, 2, 16)
+    WX_WIDE(10, 4) WX_WIDE(10, 2) WX_WIDE(8, 4) WX_WIDE(8, 2) WX_WIDE(6, 4) WX_WIDE(6, 2)
 #undef WX_WIDE
     return false;
 }
@@ -848,18 +841,17 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
         const GemmEpilogue& ep = g.ep;
         const bool plain_f32 = ep.out && ep.out_dtype == DT_F32 && !ep.bias && !ep.act && !ep.residual && !ep.rowadd && !ep.colscale_period
                                && ep.mode == 0 && !ep.out_rows_per_batch && ep.ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(ep.out) & 15) == 0;
-        static const bool wide16 = getenv("WX_WIDE16") != nullptr;
         if (g.Wpk && (g.N % 16 != 0 || (reinterpret_cast<uintptr_t>(g.Wpk) & 15))) return -1;
-        const int wcks = (!no_wide && g.n_split <= 1 && g.N >= 16384 && plain_f32) ? decode_wide_cks(g.K, wide16, &wnch) : 0;
+        const int wcks = (!no_wide && g.n_split <= 1 && g.N >= 16384 && plain_f32) ? decode_wide_cks(g.K, &wnch) : 0;
         if (g.M <= DG_MAX_ROWS && g.a_rows_per_batch == 0 && wcks) {
-            const int nunits = (g.N + 15) / 16, nw = wide16 ? 16 : 8, blocks = nunits / nw < 256 ? nunits / nw : 256;     // one workgroup per CU
+            const int nunits = (g.N + 15) / 16, blocks = nunits / 8 < 256 ? nunits / 8 : 256;     // one workgroup per CU
             bool ok;
             switch ((g.M + 15) / 16) {
-                case 1: ok = launch_decode_wide<1>(g, wcks, wnch, wide16, blocks, st); break;
-                case 2: ok = launch_decode_wide<2>(g, wcks, wnch, wide16, blocks, st); break;
-                case 3: ok = launch_decode_wide<3>(g, wcks, wnch, wide16, blocks, st); break;
-                case 4: ok = launch_decode_wide<4>(g, wcks, wnch, wide16, blocks, st); break;
-                default: ok = launch_decode_wide<5>(g, wcks, wnch, wide16, blocks, st); break;
+                case 1: ok = launch_decode_wide<1>(g, wcks, wnch, blocks, st); break;
+                case 2: ok = launch_decode_wide<2>(g, wcks, wnch, blocks, st); break;
+                case 3: ok = launch_decode_wide<3>(g, wcks, wnch, blocks, st); break;
+                case 4: ok = launch_decode_wide<4>(g, wcks, wnch, blocks, st); break;
+                default: ok = launch_decode_wide<5>(g, wcks, wnch, blocks, st); break;
             }
             if (!ok) return -1;
         } else if (g.M <= DG_MAX_ROWS && g.a_rows_per_batch == 0 && cks) {
