@@ -160,7 +160,9 @@ int wx_decoder_logits(wx_engine* e, int32_t B, const int32_t* d_tokens, int32_t 
 /* result of the last profiled wx_decode_greedy: summed HIP-event time of the bracketed cross-attention launches */
 int wx_get_profile(wx_engine* e, double* total_ms, int64_t* launches);
 
-/* introspection for benchmarks */
+/* introspection for benchmarks.  wx_weight_bytes counts what wx_finalize left resident: the weights in the engine dtype and,
+ * on bf16 engines, a second copy of the decoder projections and the token embedding in the load order of the decode GEMMs
+ * (about half as much again). */
 int64_t wx_weight_bytes(wx_engine* e);
 int64_t wx_workspace_bytes(wx_engine* e);
 
