@@ -469,7 +469,17 @@ __global__ __launch_bounds__(SAMP_NT) void sampler_kernel(SamplerArgs s) {
     __shared__ float sh_f[SAMP_NW], sh_g[SAMP_NW];
     __shared__ int sh_flags[8];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int t0 = *s.d_pos;
+    // The position moves on once every workgroup has READ it, which is all the ticket guards -- so it is drawn here, where
+    // its round trip hides behind the row scan, not at the end of the kernel.  One lane reads the position for the whole
+    // workgroup, and the ticket's operand depends on the value read, so the atomic cannot be issued ahead of that load.
+    if (tid == 0) {
+        const int p = *s.d_pos;
+        sh_flags[7] = p;
+        const int ticket = atomicAdd(s.d_block_counter, p >= 0 ? 1 : 2);      // always 1
+        if (ticket == s.B - 1) { *s.d_block_counter = 0; *s.d_pos = p + s.group; }
+    }
+    __syncthreads();
+    const int t0 = sh_flags[7];
     const int b = blockIdx.x / s.group, t = t0 + blockIdx.x % s.group;     // group > 1: forced prompt pass, one row per position
     const float* lg = s.logits + (int64_t)blockIdx.x * s.ldl;
     const int V = s.n_vocab;
@@ -537,6 +547,9 @@ __global__ __launch_bounds__(SAMP_NT) void sampler_kernel(SamplerArgs s) {
         const int a_lo = sh_flags[0], a_hi = sh_flags[1], b_lo = sh_flags[2], b_hi = sh_flags[3], c_hi = sh_flags[4], d_lo = sh_flags[5];
         const bool ts_mode = !s.without_timestamps;
         const bool blank_rule = first_step && s.suppress_blank;
+        // what the last lane standing needs at the very end is fetched now, behind the scan
+        const int prev_id = row[t];
+        const float prev_sum = s.sum_logprob[b];
         const bool sampling = temperature > 0.f;
         const float inv_t = sampling ? 1.0f / temperature : 1.0f;
         Pick best_all{-INFINITY, 0x7fffffff, -INFINITY}, best_ts{-INFINITY, 0x7fffffff, -INFINITY};
@@ -571,12 +584,29 @@ __global__ __launch_bounds__(SAMP_NT) void sampler_kernel(SamplerArgs s) {
         ms_all = wave_ms(ms_all); ms_ts = wave_ms(ms_ts);
         if (lane == 0) { sh_all[wid] = best_all; sh_ts[wid] = best_ts; sh_f[wid] = max_text; sh_msa[wid] = ms_all; sh_mst[wid] = ms_ts; }
         __syncthreads();
-        if (tid == 0) {
-            for (int w = 1; w < SAMP_NW; ++w) {
-                best_all = pick_better(best_all, sh_all[w]); best_ts = pick_better(best_ts, sh_ts[w]);
-                max_text = fmaxf(max_text, sh_f[w]);
-                ms_all = ms_merge(ms_all, sh_msa[w]); ms_ts = ms_merge(ms_ts, sh_mst[w]);
+        if (wid == 0) {
+            // the 16 per-wave results, one per lane, merged by a fixed 4-step butterfly (lanes >= 16 carry neutral elements)
+            const bool has = lane < SAMP_NW;
+            best_all = has ? sh_all[lane] : Pick{-INFINITY, 0x7fffffff, -INFINITY};
+            best_ts = has ? sh_ts[lane] : Pick{-INFINITY, 0x7fffffff, -INFINITY};
+            max_text = has ? sh_f[lane] : -INFINITY;
+            ms_all = has ? sh_msa[lane] : MS{-INFINITY, 0.f};
+            ms_ts = has ? sh_mst[lane] : MS{-INFINITY, 0.f};
+#pragma unroll
+            for (int off = SAMP_NW / 2; off >= 1; off >>= 1) {
+                Pick pa, pt; MS ma, mt;
+                pa.key = __shfl_xor(best_all.key, off); pa.i = __shfl_xor(best_all.i, off); pa.raw = __shfl_xor(best_all.raw, off);
+                pt.key = __shfl_xor(best_ts.key, off); pt.i = __shfl_xor(best_ts.i, off); pt.raw = __shfl_xor(best_ts.raw, off);
+                ma.m = __shfl_xor(ms_all.m, off); ma.s = __shfl_xor(ms_all.s, off);
+                mt.m = __shfl_xor(ms_ts.m, off); mt.s = __shfl_xor(ms_ts.s, off);
+                const bool low = (lane & off) == 0;             // merge as (lower lane's value, upper lane's value) on both sides
+                best_all = pick_better(best_all, pa); best_ts = pick_better(best_ts, pt);
+                max_text = fmaxf(max_text, __shfl_xor(max_text, off));
+                ms_all = low ? ms_merge(ms_all, ma) : ms_merge(ma, ms_all);
+                ms_ts = low ? ms_merge(ms_ts, mt) : ms_merge(mt, ms_ts);
             }
+        }
+        if (tid == 0) {
             // log-probabilities are always those of the UNSCALED filtered logits (upstream GreedyDecoder.update)
             const float lse_all = ms_all.m + logf(ms_all.s);
             int chosen = best_all.i;
@@ -586,18 +616,13 @@ __global__ __launch_bounds__(SAMP_NT) void sampler_kernel(SamplerArgs s) {
                 const float ts_lp = lse_ts - lse_all, text_lp = max_text - lse_all;
                 if (ts_lp > text_lp) { chosen = best_ts.i; logprob = best_ts.raw - lse_ts; }   // only timestamps remain
             }
-            const bool alive = row[t] != s.tok_eot;
-            if (alive) s.sum_logprob[b] += logprob;
+            const bool alive = prev_id != s.tok_eot;
+            if (alive) s.sum_logprob[b] = prev_sum + logprob;
             const int next = alive ? chosen : s.tok_eot;
             row[t + 1] = next;
             if (alive && next == s.tok_eot) atomicAdd(s.n_finished, 1);
         }
         }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const int ticket = atomicAdd(s.d_block_counter, 1);
-        if (ticket == s.B - 1) { *s.d_block_counter = 0; *s.d_pos = t0 + s.group; }
     }
 }
 
