@@ -177,6 +177,10 @@ struct SamplerArgs {
     // when set, {temperature bits, seed, sample_len} are read from device memory instead, so a captured decode-step graph
     // stays valid across calls that only change them (temperature fallback re-decodes the same window)
     const uint32_t* dyn = nullptr;
+    // sampling steps only: `parts` workgroups scan a row (1, 2, 4 or 8) and leave records in part_buf [B][parts][16] floats
+    // for a small finishing launch; 1 = one workgroup per row does everything
+    int parts = 1;
+    float* part_buf = nullptr;
 };
 int launch_sampler(const SamplerArgs& s, hipStream_t st);
 // n_tokens[b] = sampled ids before the first EOT; the tail of every row is EOT padded.  row_n_prompt may be null.

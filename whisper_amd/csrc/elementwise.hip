@@ -463,30 +463,70 @@ __device__ __forceinline__ float uniform01(uint32_t seed, uint32_t row, uint32_t
     return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
 }
 
+// last step of a row's sampling: choose between the best candidate overall and the best timestamp, score it, write the id
+__device__ __forceinline__ void sampler_commit(const SamplerArgs& s, int b, int t, bool ts_mode, Pick best_all, Pick best_ts,
+                                               float max_text, MS ms_all, MS ms_ts, int prev_id, float prev_sum) {
+    // log-probabilities are always those of the UNSCALED filtered logits (upstream GreedyDecoder.update)
+    const float lse_all = ms_all.m + logf(ms_all.s);
+    int chosen = best_all.i;
+    float logprob = best_all.raw - lse_all;
+    if (ts_mode && ms_ts.m > -INFINITY) {
+        const float lse_ts = ms_ts.m + logf(ms_ts.s);
+        const float ts_lp = lse_ts - lse_all, text_lp = max_text - lse_all;
+        if (ts_lp > text_lp) { chosen = best_ts.i; logprob = best_ts.raw - lse_ts; }   // only timestamps remain
+    }
+    const bool alive = prev_id != s.tok_eot;
+    if (alive) s.sum_logprob[b] = prev_sum + logprob;
+    const int next = alive ? chosen : s.tok_eot;
+    s.tokens[(int64_t)b * s.ld_tok + t + 1] = next;
+    if (alive && next == s.tok_eot) atomicAdd(s.n_finished, 1);
+}
+// one butterfly step over (Pick, Pick, max, MS, MS): merge as (lower lane's value, upper lane's value) on both sides
+__device__ __forceinline__ void sampler_butterfly(int lane, int off, Pick& best_all, Pick& best_ts, float& max_text, MS& ms_all, MS& ms_ts) {
+    Pick pa, pt; MS ma, mt;
+    pa.key = __shfl_xor(best_all.key, off); pa.i = __shfl_xor(best_all.i, off); pa.raw = __shfl_xor(best_all.raw, off);
+    pt.key = __shfl_xor(best_ts.key, off); pt.i = __shfl_xor(best_ts.i, off); pt.raw = __shfl_xor(best_ts.raw, off);
+    ma.m = __shfl_xor(ms_all.m, off); ma.s = __shfl_xor(ms_all.s, off);
+    mt.m = __shfl_xor(ms_ts.m, off); mt.s = __shfl_xor(ms_ts.s, off);
+    const bool low = (lane & off) == 0;
+    best_all = pick_better(best_all, pa); best_ts = pick_better(best_ts, pt);
+    max_text = fmaxf(max_text, __shfl_xor(max_text, off));
+    ms_all = low ? ms_merge(ms_all, ma) : ms_merge(ma, ms_all);
+    ms_ts = low ? ms_merge(ms_ts, mt) : ms_merge(mt, ms_ts);
+}
+constexpr int SAMP_REC = 16;          // floats per (row, part) record of the two-launch form
+
+// s.parts == 1: one workgroup per row scans it and commits the id.  s.parts == P > 1 (sampling steps only): the scan is VALU
+// bound (~45 instructions per vocabulary entry), so P workgroups share a row, each leaves a record in s.part_buf, and
+// sampler_finish_kernel merges the P records and commits -- one more (tiny) launch, the scan on 4x the CUs.
 __global__ __launch_bounds__(SAMP_NT) void sampler_kernel(SamplerArgs s) {
     __shared__ Pick sh_all[SAMP_NW], sh_ts[SAMP_NW];
     __shared__ MS sh_msa[SAMP_NW], sh_mst[SAMP_NW];
     __shared__ float sh_f[SAMP_NW], sh_g[SAMP_NW];
     __shared__ int sh_flags[8];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int P = s.parts, rb = blockIdx.x / P, part = blockIdx.x % P;
     // The position moves on once every workgroup has READ it, which is all the ticket guards -- so it is drawn here, where
     // its round trip hides behind the row scan, not at the end of the kernel.  One lane reads the position for the whole
     // workgroup, and the ticket's operand depends on the value read, so the atomic cannot be issued ahead of that load.
+    // (With P > 1 the finishing kernel still needs the position: it draws the tickets.)
     if (tid == 0) {
         const int p = *s.d_pos;
         sh_flags[7] = p;
-        const int ticket = atomicAdd(s.d_block_counter, p >= 0 ? 1 : 2);      // always 1
-        if (ticket == s.B - 1) { *s.d_block_counter = 0; *s.d_pos = p + s.group; }
+        if (P == 1) {
+            const int ticket = atomicAdd(s.d_block_counter, p >= 0 ? 1 : 2);      // always 1
+            if (ticket == s.B - 1) { *s.d_block_counter = 0; *s.d_pos = p + s.group; }
+        }
     }
     __syncthreads();
     const int t0 = sh_flags[7];
-    const int b = blockIdx.x / s.group, t = t0 + blockIdx.x % s.group;     // group > 1: forced prompt pass, one row per position
-    const float* lg = s.logits + (int64_t)blockIdx.x * s.ldl;
+    const int b = rb / s.group, t = t0 + rb % s.group;     // group > 1: forced prompt pass, one row per position
+    const float* lg = s.logits + (int64_t)rb * s.ldl;
     const int V = s.n_vocab;
     const int n_prompt = s.row_n_prompt ? s.row_n_prompt[b] : s.n_prompt;
     const int sot_index = s.row_sot ? s.row_sot[b] : s.sot_index;
 
-    if (t == sot_index && s.no_speech) {
+    if (t == sot_index && s.no_speech && part == 0) {
         float mx = -INFINITY;
         for (int i = tid; i < V; i += SAMP_NT) mx = fmaxf(mx, lg[i]);
         mx = wave_max(mx);
@@ -518,7 +558,7 @@ __global__ __launch_bounds__(SAMP_NT) void sampler_kernel(SamplerArgs s) {
         int row_cap = s.ld_tok - n_prompt; if (row_cap > sample_len) row_cap = sample_len;
         if (cnt >= row_cap) {
             // upstream stops this window at sample_len / n_ctx: the row is closed with EOT (not counted, not scored)
-            if (tid == 0) {
+            if (tid == 0 && P == 1) {
                 const bool alive = row[t] != s.tok_eot;
                 row[t + 1] = s.tok_eot;
                 if (alive && cnt == row_cap) atomicAdd(s.n_finished, 1);
@@ -556,7 +596,7 @@ __global__ __launch_bounds__(SAMP_NT) void sampler_kernel(SamplerArgs s) {
         MS ms_all{-INFINITY, 0.f}, ms_ts{-INFINITY, 0.f};
         float max_text = -INFINITY;
         // suppress[] is padded to a multiple of 4 bytes (wx_finalize), logits rows to 16 floats
-        for (int i0 = tid * 4; i0 < V; i0 += SAMP_NT * 4) {
+        for (int i0 = (part * SAMP_NT + tid) * 4; i0 < V; i0 += P * SAMP_NT * 4) {
             const f32x4 v4 = *reinterpret_cast<const f32x4*>(lg + i0);
             const uint32_t sup = *reinterpret_cast<const uint32_t*>(s.suppress + i0);
 #pragma unroll
@@ -593,43 +633,62 @@ __global__ __launch_bounds__(SAMP_NT) void sampler_kernel(SamplerArgs s) {
             ms_all = has ? sh_msa[lane] : MS{-INFINITY, 0.f};
             ms_ts = has ? sh_mst[lane] : MS{-INFINITY, 0.f};
 #pragma unroll
-            for (int off = SAMP_NW / 2; off >= 1; off >>= 1) {
-                Pick pa, pt; MS ma, mt;
-                pa.key = __shfl_xor(best_all.key, off); pa.i = __shfl_xor(best_all.i, off); pa.raw = __shfl_xor(best_all.raw, off);
-                pt.key = __shfl_xor(best_ts.key, off); pt.i = __shfl_xor(best_ts.i, off); pt.raw = __shfl_xor(best_ts.raw, off);
-                ma.m = __shfl_xor(ms_all.m, off); ma.s = __shfl_xor(ms_all.s, off);
-                mt.m = __shfl_xor(ms_ts.m, off); mt.s = __shfl_xor(ms_ts.s, off);
-                const bool low = (lane & off) == 0;             // merge as (lower lane's value, upper lane's value) on both sides
-                best_all = pick_better(best_all, pa); best_ts = pick_better(best_ts, pt);
-                max_text = fmaxf(max_text, __shfl_xor(max_text, off));
-                ms_all = low ? ms_merge(ms_all, ma) : ms_merge(ma, ms_all);
-                ms_ts = low ? ms_merge(ms_ts, mt) : ms_merge(mt, ms_ts);
-            }
+            for (int off = SAMP_NW / 2; off >= 1; off >>= 1) sampler_butterfly(lane, off, best_all, best_ts, max_text, ms_all, ms_ts);
         }
         if (tid == 0) {
-            // log-probabilities are always those of the UNSCALED filtered logits (upstream GreedyDecoder.update)
-            const float lse_all = ms_all.m + logf(ms_all.s);
-            int chosen = best_all.i;
-            float logprob = best_all.raw - lse_all;
-            if (ts_mode && ms_ts.m > -INFINITY) {
-                const float lse_ts = ms_ts.m + logf(ms_ts.s);
-                const float ts_lp = lse_ts - lse_all, text_lp = max_text - lse_all;
-                if (ts_lp > text_lp) { chosen = best_ts.i; logprob = best_ts.raw - lse_ts; }   // only timestamps remain
+            if (P == 1) {
+                sampler_commit(s, b, t, ts_mode, best_all, best_ts, max_text, ms_all, ms_ts, prev_id, prev_sum);
+            } else {
+                float* rec = s.part_buf + ((int64_t)rb * P + part) * SAMP_REC;
+                rec[0] = best_all.key; rec[1] = __int_as_float(best_all.i); rec[2] = best_all.raw;
+                rec[3] = best_ts.key; rec[4] = __int_as_float(best_ts.i); rec[5] = best_ts.raw;
+                rec[6] = max_text; rec[7] = ms_all.m; rec[8] = ms_all.s; rec[9] = ms_ts.m; rec[10] = ms_ts.s;
             }
-            const bool alive = prev_id != s.tok_eot;
-            if (alive) s.sum_logprob[b] = prev_sum + logprob;
-            const int next = alive ? chosen : s.tok_eot;
-            row[t + 1] = next;
-            if (alive && next == s.tok_eot) atomicAdd(s.n_finished, 1);
         }
         }
     }
 }
 
+// second launch of the P > 1 form: one wave per row merges the P records (same butterfly) and commits; draws the tickets
+__global__ __launch_bounds__(64) void sampler_finish_kernel(SamplerArgs s) {
+    const int lane = threadIdx.x, b = blockIdx.x, P = s.parts;
+    const int t = *s.d_pos;                                  // wave-uniform; the ticket below depends on it
+    if (lane == 0) {
+        const int ticket = atomicAdd(s.d_block_counter, t >= 0 ? 1 : 2);          // always 1
+        if (ticket == s.B - 1) { *s.d_block_counter = 0; *s.d_pos = t + 1; }
+    }
+    const int n_prompt = s.row_n_prompt ? s.row_n_prompt[b] : s.n_prompt;
+    if (!(t >= n_prompt - 1 && t + 1 < s.ld_tok)) return;
+    int32_t* row = s.tokens + (int64_t)b * s.ld_tok;
+    const int cnt = t - n_prompt + 1;
+    const int sample_len = s.dyn ? (int)s.dyn[2] : s.sample_len;
+    int row_cap = s.ld_tok - n_prompt; if (row_cap > sample_len) row_cap = sample_len;
+    const int prev_id = row[t];
+    if (cnt >= row_cap) {
+        if (lane == 0) {
+            row[t + 1] = s.tok_eot;
+            if (prev_id != s.tok_eot && cnt == row_cap) atomicAdd(s.n_finished, 1);
+        }
+        return;
+    }
+    const float prev_sum = s.sum_logprob[b];
+    const bool has = lane < P;
+    const float* rec = s.part_buf + ((int64_t)b * P + (has ? lane : 0)) * SAMP_REC;
+    Pick best_all = has ? Pick{rec[0], __float_as_int(rec[1]), rec[2]} : Pick{-INFINITY, 0x7fffffff, -INFINITY};
+    Pick best_ts = has ? Pick{rec[3], __float_as_int(rec[4]), rec[5]} : Pick{-INFINITY, 0x7fffffff, -INFINITY};
+    float max_text = has ? rec[6] : -INFINITY;
+    MS ms_all = has ? MS{rec[7], rec[8]} : MS{-INFINITY, 0.f};
+    MS ms_ts = has ? MS{rec[9], rec[10]} : MS{-INFINITY, 0.f};
+    for (int off = P / 2; off >= 1; off >>= 1) sampler_butterfly(lane, off, best_all, best_ts, max_text, ms_all, ms_ts);
+    if (lane == 0) sampler_commit(s, b, t, !s.without_timestamps, best_all, best_ts, max_text, ms_all, ms_ts, prev_id, prev_sum);
+}
+
 int launch_sampler(const SamplerArgs& s, hipStream_t st) {
     if (s.B <= 0 || !s.logits || !s.tokens || !s.d_pos || !s.d_block_counter || !s.suppress) return -1;
     if (s.group < 1 || (s.group > 1 && (!s.forced || s.B % s.group))) return -1;
-    hipLaunchKernelGGL(sampler_kernel, dim3(s.B), dim3(SAMP_NT), 0, st, s);
+    if (s.parts != 1 && (s.forced || s.group != 1 || !s.part_buf || (s.parts != 2 && s.parts != 4 && s.parts != 8))) return -1;
+    hipLaunchKernelGGL(sampler_kernel, dim3(s.B * s.parts), dim3(SAMP_NT), 0, st, s);
+    if (s.parts > 1) hipLaunchKernelGGL(sampler_finish_kernel, dim3(s.B), dim3(64), 0, st, s);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -82,7 +82,7 @@ struct wx_engine {
     int32_t *tokens = nullptr, *d_pos = nullptr, *d_counter = nullptr, *n_finished = nullptr, *n_tokens = nullptr;
     int32_t *row_n_prompt = nullptr, *row_sot = nullptr;      // per-row prompt length / SOT position
     uint32_t* dyn = nullptr;                                 // {temperature bits, seed, sample_len} read by the sampler
-    float *sum_logprob = nullptr, *no_speech = nullptr, *partial = nullptr, *gpartial = nullptr;
+    float *sum_logprob = nullptr, *no_speech = nullptr, *partial = nullptr, *gpartial = nullptr, *samp_part = nullptr;
     int32_t* h_pinned = nullptr;
     float* rs_taps = nullptr;                                // resampler taps (wx_resample_pcm16), RS_MAX_TAPS floats
     int encoded_B = 0;
@@ -483,6 +483,7 @@ int wx_finalize(wx_engine* e) {
     if ((r = A((void**)&e->no_speech, (size_t)B * 4))) return r;
     if ((r = A((void**)&e->partial, (size_t)B * e->Ht * 8 * (HEAD_DIM + 2) * 4))) return r;
     if ((r = A((void**)&e->gpartial, (size_t)16 * B * 3 * d * 4))) return r;   // split-K partial tiles of the decode GEMMs
+    if ((r = A((void**)&e->samp_part, (size_t)B * 8 * 16 * 4))) return r;       // sampler records [row][part <= 8][16]
     {   // beam search
         const size_t ctx = c.n_text_ctx, lt = e->ld_tok;
         if ((r = A((void**)&e->b_tokens_tmp, (size_t)B * lt * 4))) return r;
@@ -871,7 +872,11 @@ static SamplerArgs make_sampler(wx_engine* e, int B, const wx_decode_opts& o, in
     s.tok_no_timestamps = c.tok_no_timestamps; s.tok_timestamp_begin = c.tok_timestamp_begin;
     s.without_timestamps = o.without_timestamps; s.suppress_blank = o.suppress_blank; s.max_initial_ts = o.max_initial_timestamp_index;
     s.forced = forced;
-    if (!forced) { s.row_n_prompt = e->row_n_prompt; s.row_sot = e->row_sot; s.dyn = e->dyn; }
+    if (!forced) {
+        s.row_n_prompt = e->row_n_prompt; s.row_sot = e->row_sot; s.dyn = e->dyn;
+        static const int parts_env = getenv("WX_SAMPLER_PARTS") ? atoi(getenv("WX_SAMPLER_PARTS")) : 4;
+        if ((parts_env == 2 || parts_env == 4 || parts_env == 8) && B <= c.max_batch) { s.parts = parts_env; s.part_buf = e->samp_part; }
+    }
     return s;
 }
 
