@@ -201,18 +201,28 @@ __global__ __launch_bounds__(64) void beam_select_kernel(BeamArgs s) {
         if (tid < n) { s.src[r0 + tid] = r0 + tid; s.next_tok[r0 + tid] = s.tokens[(int64_t)(r0 + tid) * s.ld_tok + t + 1]; s.sum_tmp[r0 + tid] = s.sum_logprob[r0 + tid]; }
         return;
     }
+    // every lane fetches candidates (one round trip for all of them), one lane then walks them in LDS
+    __shared__ float sh_sc[8 * BEAM_MAXK], sh_wsc[8 * BEAM_MAXK];
+    __shared__ int sh_tk[8 * BEAM_MAXK], sh_wtk[8 * BEAM_MAXK], sh_wsr[8 * BEAM_MAXK], sh_word[8 * BEAM_MAXK];
+    for (int q = tid; q < n * (n + 1); q += 64) {
+        const int j = q / (n + 1), k = q % (n + 1);
+        sh_sc[j * BEAM_MAXK + k] = s.cand_score[(int64_t)(r0 + j) * BEAM_MAXK + k];
+        sh_tk[j * BEAM_MAXK + k] = s.cand_tok[(int64_t)(r0 + j) * BEAM_MAXK + k];
+    }
+    __syncthreads();
     if (tid == 0) {
         const bool first_step = (t == s.n_prompt - 1);
         // candidates in upstream's insertion order (beam-major, proposal rank); at the first step every beam holds the
         // same prefix and the same logits, so the sequence-keyed dict keeps one beam's proposals only
-        float sc[8 * BEAM_MAXK]; int tk[8 * BEAM_MAXK]; int sr[8 * BEAM_MAXK]; int ord[8 * BEAM_MAXK];
+        // (work arrays in LDS: dynamically indexed private arrays live in scratch memory, a cache round trip per access)
+        float* sc = sh_wsc; int *tk = sh_wtk, *sr = sh_wsr, *ord = sh_word;
         int nc = 0;
         const int nb = first_step ? 1 : n;
         for (int j = 0; j < nb; ++j)
             for (int k = 0; k < n + 1; ++k) {
-                const float v = s.cand_score[(int64_t)(r0 + j) * BEAM_MAXK + k];
+                const float v = sh_sc[j * BEAM_MAXK + k];
                 if (v == -INFINITY) continue;
-                sc[nc] = v; tk[nc] = s.cand_tok[(int64_t)(r0 + j) * BEAM_MAXK + k]; sr[nc] = r0 + j; ord[nc] = nc; ++nc;
+                sc[nc] = v; tk[nc] = sh_tk[j * BEAM_MAXK + k]; sr[nc] = r0 + j; ord[nc] = nc; ++nc;
             }
         for (int i = 1; i < nc; ++i) {                              // stable insertion sort, score descending
             const int o = ord[i]; int j = i - 1;
