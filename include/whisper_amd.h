@@ -70,6 +70,9 @@ int wx_create(const wx_config* cfg, wx_engine** out);
 void wx_destroy(wx_engine* e);
 int wx_set_weight(wx_engine* e, const char* name, const float* h_data, const int64_t* shape, int32_t ndim);
 int wx_set_mel_filters(wx_engine* e, const float* h_filters /* [n_mels][201] */);
+/* the ids DecodingTask._get_suppress_tokens resolves (upstream suppress_tokens="-1": the vocabulary's non-speech symbols
+ * + the task / control tokens).  May be called again after wx_finalize: the device mask is replaced once the engine's
+ * device is idle (blocking); it must not be called while a decode call on this engine is running. */
 int wx_set_suppress_tokens(wx_engine* e, const int32_t* h_ids, int32_t n);
 int wx_finalize(wx_engine* e);
 
@@ -141,14 +144,16 @@ int wx_decode_rows(wx_engine* e, int32_t B, const int32_t* h_prompts, const int3
  * sets them -- ref:speech_recognition.py:48-52 -- but BASELINE.json configs[3] does) for the B windows of the last
  * wx_encode.  Rows = B x beam_size must fit max_batch.  The device runs upstream's update() every step: per window the
  * beam_size+1 best continuations of every beam, visited best first, EOT candidates appended to the window's finished
- * list while it holds fewer than max_candidates = round(beam_size * patience) entries, the first beam_size others kept as
- * beams; decoding stops when every window's list is full (or at sample_len).  The self-attention cache follows the
+ * list while it holds fewer than max_candidates entries, the first beam_size others kept as beams; decoding stops when
+ * every window's list is full (or at sample_len).  max_candidates is upstream's round(beam_size * patience), computed by
+ * the CALLER (Python's round: double arithmetic, ties to even) because it also sizes the caller's buffers below; it must
+ * lie in [beam_size, 2 * beam_size] (patience 1 ... 2).  The self-attention cache follows the
  * beams through index rows (no K/V copy); the beams of a window share one pass over its cross-attention K/V.
  * Outputs (device): d_fin_tokens [B][max_candidates][n_text_ctx + 1] (prompt + ids + EOT padding, in finished order),
  * d_fin_sum_logprob [B][max_candidates], d_fin_count [B], and the live beams d_beam_tokens [B*beam_size][n_text_ctx + 1],
  * d_beam_sum_logprob [B*beam_size] -- upstream finalize() (top up short lists from the beams) and the
  * sum_logprob / length ranking are a few dozen host operations and are left to the caller (whisper_amd/engine.py). */
-int wx_decode_beam(wx_engine* e, int32_t B, int32_t beam_size, float patience, const int32_t* h_prompt,
+int wx_decode_beam(wx_engine* e, int32_t B, int32_t beam_size, int32_t max_candidates, const int32_t* h_prompt,
                    const wx_decode_opts* opts, int32_t* d_fin_tokens, float* d_fin_sum_logprob, int32_t* d_fin_count,
                    int32_t* d_beam_tokens, float* d_beam_sum_logprob, float* d_no_speech_prob, int32_t* h_steps,
                    void* stream);

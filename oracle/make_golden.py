@@ -9,9 +9,15 @@ Two kinds of vectors are written:
                    synthetic weights; no ``from_pretrained``, no network).  These pin oracle/whisper_oracle.py.
                    openai-whisper itself (the reference's dependency) is not installable here, so against it parity is
                    unpinned; transformers documents 1e-5 agreement of its feature extractor with the original.
-  * ``oracle_*`` — outputs of the oracle itself for the decoding rules (greedy ids, log-probs, margins), which the HF
-                   generate() stack does not reproduce one-to-one; they pin the HIP path on the GPU box and guard the
-                   oracle against regressions.
+  * ``hf_rules`` / ``hf_greedy_*`` — the decoding RULES from transformers' own logits processors
+                   (``SuppressTokensAtBeginLogitsProcessor``, ``SuppressTokensLogitsProcessor``,
+                   ``WhisperTimeStampLogitsProcessor``, ``WhisperNoSpeechDetection``, hf:generation/logits_process.py:
+                   1816-2112): masks / argmax on seeded logit rows and token histories that reach every branch, and a
+                   greedy loop (HF model forward + HF processors, argmax, EOT stickiness) on the seeded micro model.
+                   They pin ``apply_logit_filters`` / ``greedy_decode`` of the oracle to an independent implementation.
+  * ``oracle_*`` — outputs of the oracle itself (greedy ids, log-probs, margins); they pin the HIP path on the GPU box
+                   and guard the oracle against regressions.  Beam search and the sequential long-form loop have no
+                   independent implementation in this container (transformers' differ by design): [upstream-recall] only.
 Inputs are regenerated from seeds at test time (whisper_amd.checkpoint.synthetic_state_dict, oracle.varied_audio), so
 the fixtures hold outputs only and stay small.
 """
@@ -56,6 +62,123 @@ def build_hf(dims, sd):
     res = m.load_state_dict(hsd, strict=False)
     assert not res.missing_keys and not res.unexpected_keys, res
     return m
+
+
+def rule_cases(tok, n_vocab):
+    """Token histories (after the prompt) and logit shaping for the decoding-rule fixtures: every branch of the timestamp
+    rules, with and without the "timestamps outweigh every text token" override."""
+    tb = tok.timestamp_begin
+    hist = [
+        [],                                   # first sampled position: only timestamps <= max_initial survive; blank/eot masked
+        [tb + 0],                             # <ts>: penultimate counts as timestamp -> must be text next
+        [tb + 10, 500],                       # <ts> text: timestamps below the last one are forbidden
+        [tb + 1, 500, tb + 20],               # text <ts>: next must be a timestamp (>= last) or EOT
+        [tb + 1, tb + 20],                    # <ts><ts>: next must be text
+        [tb + 3, 400, 401, tb + 40, tb + 40, 77],      # second segment running
+        [tb + 3, 400, 401, tb + 40, tb + 40],          # second segment just opened
+        [tb + 1499],                                    # last timestamp of the window
+        [tb + 5, 300, tb + 1500],                       # text then <|30.00|>
+        [600, 601],                                     # no timestamp yet past the first position (prompted continuation)
+    ]
+    cases = []
+    for h in hist:
+        for boost_ts in (0.0, 14.0):          # 14: the timestamp mass outweighs the best text token -> override fires
+            cases.append((h, boost_ts))
+    return cases
+
+
+def rule_logits(seed: int, n_vocab: int, tok, boost_ts: float) -> torch.Tensor:
+    g = torch.Generator().manual_seed(seed)
+    lg = torch.randn(n_vocab, generator=g) * 3.0
+    if boost_ts:
+        lg[tok.timestamp_begin:] += boost_ts
+    return lg
+
+
+def hf_processors(tok, sup, begin_index, max_initial=50):
+    import types
+    from transformers.generation.logits_process import (LogitsProcessorList, SuppressTokensAtBeginLogitsProcessor,
+                                                        SuppressTokensLogitsProcessor, WhisperTimeStampLogitsProcessor)
+    gc = types.SimpleNamespace(eos_token_id=tok.eot, bos_token_id=tok.eot, no_timestamps_token_id=tok.no_timestamps,
+                               max_initial_timestamp_index=max_initial)
+    plain = LogitsProcessorList([SuppressTokensAtBeginLogitsProcessor([tok.blank, tok.eot], begin_index),
+                                 SuppressTokensLogitsProcessor(sup)])
+    with_ts = LogitsProcessorList(list(plain) + [WhisperTimeStampLogitsProcessor(gc, begin_index=begin_index)])
+    return plain, with_ts
+
+
+def make_rule_fixtures():
+    """hf_rules.npz: transformers' processors on seeded logit rows (order of hf:models/whisper/generation_whisper.py:1774-1812)."""
+    from transformers.generation.logits_process import WhisperNoSpeechDetection
+    out = {}
+    for n_vocab in (51865, 51866):
+        tok = ck.special_tokens_for(n_vocab)
+        sup = wo.suppress_token_ids(tok, ck.non_speech_suppress_ids(n_vocab))
+        prompt = [tok.sot, tok.lang(0), tok.transcribe]
+        masks, argmax, lps, nsp = [], [], [], []
+        for ci, (h, boost) in enumerate(rule_cases(tok, n_vocab)):
+            lg = rule_logits(1000 + ci, n_vocab, tok, boost)
+            ids = torch.tensor([prompt + h])
+            _, procs = hf_processors(tok, sup, begin_index=len(prompt))
+            sc = procs(ids, lg[None].clone())[0]
+            masks.append(np.packbits(torch.isinf(sc).numpy()))
+            argmax.append(int(sc.argmax()))
+            lps.append(float(torch.log_softmax(sc.float(), -1)[sc.argmax()]))
+            det = WhisperNoSpeechDetection(no_speech_token=tok.no_speech, begin_index=1)
+            det(torch.tensor([[tok.sot]]), lg[None].clone())
+            nsp.append(float(det.no_speech_prob[0]))
+        out[f"mask_{n_vocab}"] = np.stack(masks)
+        out[f"argmax_{n_vocab}"] = np.asarray(argmax, np.int32)
+        out[f"logprob_{n_vocab}"] = np.asarray(lps, np.float32)
+        out[f"no_speech_{n_vocab}"] = np.asarray(nsp, np.float32)
+    np.savez_compressed(os.path.join(OUT, "hf_rules.npz"), **out)
+
+
+def make_hf_greedy(name="micro", n_windows=4):
+    """hf_greedy_<name>.npz: greedy decoding with the HF model forward and the HF logits processors; the loop around them
+    (argmax, sum of log-probabilities while alive, EOT stickiness, stop when all rows ended) is upstream's GreedyDecoder."""
+    from transformers.generation.logits_process import WhisperNoSpeechDetection
+    dims = ck.dims_for(name)
+    sd = ck.synthetic_state_dict(dims, seed=0, eot_boost=3.0)
+    tok = ck.special_tokens_for(dims.n_vocab)
+    sup = wo.suppress_token_ids(tok, ck.non_speech_suppress_ids(dims.n_vocab))
+    hf = build_hf(dims, sd)
+    mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(s), dims.n_mels, padding=wo.N_SAMPLES)[:, :wo.N_FRAMES] for s in range(n_windows)])
+    out = {"suppress_ids": np.asarray(sup, np.int32)}
+    with torch.no_grad():
+        enc = hf.model.encoder(mels)
+        for mode, wts, n_new in (("plain", True, 40), ("ts", False, 48)):
+            init = wo.initial_tokens(tok, 0, without_timestamps=wts)
+            plain, with_ts = hf_processors(tok, sup, begin_index=len(init))
+            procs = plain if wts else with_ts
+            ids = torch.tensor([init] * n_windows)
+            sums = torch.zeros(n_windows)
+            nsp = None
+            for step in range(n_new):
+                lg_all = hf(encoder_outputs=enc, decoder_input_ids=ids).logits
+                if step == 0:
+                    det = WhisperNoSpeechDetection(no_speech_token=tok.no_speech, begin_index=1)
+                    det(ids[:, :1], lg_all[:, init.index(tok.sot)].clone())
+                    nsp = det.no_speech_prob.clone()
+                sc = procs(ids, lg_all[:, -1].clone())
+                nxt = sc.argmax(-1)
+                lp = torch.log_softmax(sc.float(), -1)[torch.arange(n_windows), nxt]
+                alive = ids[:, -1] != tok.eot
+                sums = sums + lp * alive
+                nxt = torch.where(alive, nxt, torch.full_like(nxt, tok.eot))
+                ids = torch.cat([ids, nxt[:, None]], 1)
+                if bool((ids[:, -1] == tok.eot).all()):
+                    break
+            body = ids[:, len(init):]
+            L = body.shape[1]
+            arr = np.full((n_windows, L), -1, np.int32)
+            for b in range(n_windows):
+                seq = body[b].tolist()
+                seq = seq[:seq.index(tok.eot)] if tok.eot in seq else seq
+                arr[b, :len(seq)] = seq
+            out.update({f"{mode}_init": np.asarray(init, np.int32), f"{mode}_ids": arr,
+                        f"{mode}_sum_logprobs": sums.numpy().astype(np.float32), f"{mode}_no_speech": nsp.numpy().astype(np.float32)})
+    np.savez_compressed(os.path.join(OUT, f"hf_greedy_{name}.npz"), **out)
 
 
 def main():
@@ -113,6 +236,8 @@ def main():
                             f"{mode}_no_speech": r["no_speech_probs"].astype(np.float32), f"{mode}_margins": margins,
                             f"{mode}_steps": r["steps"]})
         np.savez_compressed(os.path.join(OUT, f"oracle_greedy_{name}.npz"), **out)
+    make_rule_fixtures()
+    make_hf_greedy("micro")
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -207,52 +207,74 @@ class OracleWhisper:
     Decoder: hf:...modeling_whisper.py:733-795 (layer :469-503); logits via the tied embedding (:965,1080).
     Attention: q and k are each scaled by head_dim**-0.25 before the product, the softmax runs in fp32 (upstream
     ``MultiHeadAttention.qkv_attention`` non-SDPA path; HF scales q only, :304-309 — same value in exact
-    arithmetic).  The key projection has no bias (hf:...:279)."""
+    arithmetic).  The key projection has no bias (hf:...:279).
 
-    def __init__(self, dims, sd: Dict[str, torch.Tensor]):
+    ``emulate_bf16=True`` restates the SAME forward with the roundings of the engine's bf16 mode: matrix
+    weights, the token / decoder-position tables, LayerNorm outputs, scaled q / k, v, attention outputs, GELU outputs, the
+    conv-stem activations, the encoder output and the cross K/V cache are rounded to bf16 (round-to-nearest-even, what
+    ``(bf16)x`` does on the device); every product accumulates in fp32 and the residual stream stays fp32.  The encoder's
+    flash kernel also rounds the un-normalised softmax weights to bf16 for the P.V product (the row sum uses the
+    unrounded weights); the decode attention kernels keep them in fp32.  It is the yardstick for the bf16 tolerance:
+    what is left between it and the device is summation order."""
+
+    def __init__(self, dims, sd: Dict[str, torch.Tensor], emulate_bf16: bool = False):
         self.dims = dims
+        self.bf16 = bool(emulate_bf16)
         self.sd = {k: v.float() for k, v in sd.items()}
+        if self.bf16:
+            for k, v in self.sd.items():
+                if (k.endswith(".weight") and v.dim() >= 2) or k == "decoder.positional_embedding":
+                    self.sd[k] = self._r(v)
+
+    def _r(self, x: torch.Tensor) -> torch.Tensor:
+        return x.to(torch.bfloat16).float() if self.bf16 else x
 
     # -- attention ------------------------------------------------------------------------------
     def _heads(self, x, n_head):
         B, T, D = x.shape
         return x.view(B, T, n_head, D // n_head).permute(0, 2, 1, 3)
 
-    def _qkv_attention(self, q, k, v, n_head, mask=None):
+    def _qkv_attention(self, q, k, v, n_head, mask=None, round_p=False):
         D = q.shape[-1]
         scale = (D // n_head) ** -0.25
-        q = self._heads(q, n_head) * scale
-        k = self._heads(k, n_head) * scale
-        v = self._heads(v, n_head)
+        q = self._r(self._heads(q, n_head) * scale)
+        k = self._r(self._heads(k, n_head) * scale)
+        v = self._r(self._heads(v, n_head))
         qk = q @ k.transpose(-1, -2)
         if mask is not None:
             qk = qk + mask
-        w = F.softmax(qk.float(), dim=-1)
-        out = (w @ v).permute(0, 2, 1, 3).flatten(start_dim=2)
-        return out
+        if self.bf16 and round_p:
+            p = torch.exp(qk.float() - qk.float().amax(dim=-1, keepdim=True))
+            out = (self._r(p) @ v) / p.sum(dim=-1, keepdim=True)
+        else:
+            out = F.softmax(qk.float(), dim=-1) @ v
+        return self._r(out.permute(0, 2, 1, 3).flatten(start_dim=2))
 
     def _lin(self, x, prefix, bias=True):
         return F.linear(x, self.sd[prefix + ".weight"], self.sd[prefix + ".bias"] if bias else None)
 
+    def _ln(self, x, prefix):
+        return self._r(_layer_norm(x, self.sd[prefix + ".weight"], self.sd[prefix + ".bias"]))
+
     def _mlp(self, x, p):
-        return self._lin(F.gelu(self._lin(x, p + ".mlp.0")), p + ".mlp.2")
+        return self._lin(self._r(F.gelu(self._lin(x, p + ".mlp.0"))), p + ".mlp.2")
 
     # -- encoder --------------------------------------------------------------------------------
     def encode(self, mel: torch.Tensor) -> torch.Tensor:
         """mel ``[B, n_mels, 3000]`` → ``[B, 1500, d]``."""
         sd, dims = self.sd, self.dims
-        x = F.gelu(F.conv1d(mel.float(), sd["encoder.conv1.weight"], sd["encoder.conv1.bias"], padding=1))
+        x = self._r(F.gelu(F.conv1d(self._r(mel.float()), sd["encoder.conv1.weight"], sd["encoder.conv1.bias"], padding=1)))
         x = F.gelu(F.conv1d(x, sd["encoder.conv2.weight"], sd["encoder.conv2.bias"], stride=2, padding=1))
         x = x.permute(0, 2, 1)
         x = x + sd["encoder.positional_embedding"]
         for i in range(dims.n_audio_layer):
             p = f"encoder.blocks.{i}"
-            h = _layer_norm(x, sd[p + ".attn_ln.weight"], sd[p + ".attn_ln.bias"])
+            h = self._ln(x, p + ".attn_ln")
             a = self._qkv_attention(self._lin(h, p + ".attn.query"), self._lin(h, p + ".attn.key", bias=False),
-                                    self._lin(h, p + ".attn.value"), dims.n_audio_head)
+                                    self._lin(h, p + ".attn.value"), dims.n_audio_head, round_p=True)
             x = x + self._lin(a, p + ".attn.out")
-            x = x + self._mlp(_layer_norm(x, sd[p + ".mlp_ln.weight"], sd[p + ".mlp_ln.bias"]), p)
-        return _layer_norm(x, sd["encoder.ln_post.weight"], sd["encoder.ln_post.bias"])
+            x = x + self._mlp(self._ln(x, p + ".mlp_ln"), p)
+        return self._ln(x, "encoder.ln_post")
 
     # -- decoder --------------------------------------------------------------------------------
     def cross_kv(self, xa: torch.Tensor):
@@ -274,7 +296,7 @@ class OracleWhisper:
         mask = torch.full((total, total), float("-inf")).triu_(1)[offset:total, :total]
         for i in range(dims.n_text_layer):
             p = f"decoder.blocks.{i}"
-            h = _layer_norm(x, sd[p + ".attn_ln.weight"], sd[p + ".attn_ln.bias"])
+            h = self._ln(x, p + ".attn_ln")
             k_new = self._lin(h, p + ".attn.key", bias=False)
             v_new = self._lin(h, p + ".attn.value")
             if len(self_cache) <= i:
@@ -285,12 +307,12 @@ class OracleWhisper:
             a = self._qkv_attention(self._lin(h, p + ".attn.query"), self_cache[i][0], self_cache[i][1],
                                     dims.n_text_head, mask)
             x = x + self._lin(a, p + ".attn.out")
-            h = _layer_norm(x, sd[p + ".cross_attn_ln.weight"], sd[p + ".cross_attn_ln.bias"])
+            h = self._ln(x, p + ".cross_attn_ln")
             ck, cv = cross[i]
             a = self._qkv_attention(self._lin(h, p + ".cross_attn.query"), ck, cv, dims.n_text_head)
             x = x + self._lin(a, p + ".cross_attn.out")
-            x = x + self._mlp(_layer_norm(x, sd[p + ".mlp_ln.weight"], sd[p + ".mlp_ln.bias"]), p)
-        x = _layer_norm(x, sd["decoder.ln.weight"], sd["decoder.ln.bias"])
+            x = x + self._mlp(self._ln(x, p + ".mlp_ln"), p)
+        x = self._ln(x, "decoder.ln")
         return (x @ sd["decoder.token_embedding.weight"].t()).float()
 
     def logits(self, tokens: torch.Tensor, xa: torch.Tensor) -> torch.Tensor:
@@ -354,6 +376,27 @@ def apply_timestamp_rules(logits: torch.Tensor, tokens: torch.Tensor, sample_beg
             logits[k, :tb] = -np.inf
 
 
+def apply_logit_filters(logits: torch.Tensor, tokens: torch.Tensor, sample_begin: int, tok, suppress_ids: Sequence[int],
+                        without_timestamps: bool = True, suppress_blank: bool = True,
+                        max_initial_timestamp_index: Optional[int] = 50) -> None:
+    """Upstream ``DecodingTask.logit_filters`` applied in upstream's order, in place: SuppressBlank at the first sampled
+    position (hf:generation/logits_process.py:1859-1866 ``SuppressTokensAtBeginLogitsProcessor`` with (blank, eot)),
+    SuppressTokens (:1902-1906), ApplyTimestampRules (:2000-2047) when timestamps are enabled.  The HF generate stack
+    orders its processors the same way (hf:models/whisper/generation_whisper.py:1774-1812).
+    tests/golden/hf_rules.npz pins this function against those three HF classes."""
+    if suppress_blank and tokens.shape[1] == sample_begin:
+        logits[:, [tok.blank, tok.eot]] = -np.inf
+    logits[:, list(suppress_ids)] = -np.inf
+    if not without_timestamps:
+        apply_timestamp_rules(logits, tokens, sample_begin, tok, max_initial_timestamp_index)
+
+
+def no_speech_probability(logits_at_sot: torch.Tensor, tok) -> torch.Tensor:
+    """softmax of the UNFILTERED logits at the <|startoftranscript|> position, read at <|nospeech|>
+    (hf:generation/logits_process.py:2091-2112 ``WhisperNoSpeechDetection``)."""
+    return logits_at_sot.float().softmax(dim=-1)[:, tok.no_speech]
+
+
 def greedy_decode(model: OracleWhisper, xa: torch.Tensor, init_tokens: Sequence[int], tok,
                   suppress_ids: Sequence[int], max_new_tokens: Optional[int] = None,
                   without_timestamps: bool = True, suppress_blank: bool = True) -> Dict[str, object]:
@@ -384,15 +427,11 @@ def greedy_decode(model: OracleWhisper, xa: torch.Tensor, init_tokens: Sequence[
     for i in range(sample_len):
         if i == 0:
             lg_all = model.decode_step(tokens, 0, cross, cache)
-            no_speech = lg_all[:, sot_index].float().softmax(-1)[:, tok.no_speech].clone()
+            no_speech = no_speech_probability(lg_all[:, sot_index], tok).clone()
             lg = lg_all[:, -1].clone()
         else:
             lg = model.decode_step(tokens[:, -1:], tokens.shape[1] - 1, cross, cache)[:, -1].clone()
-        if suppress_blank and tokens.shape[1] == sample_begin:
-            lg[:, [tok.blank, tok.eot]] = -np.inf
-        lg[:, list(suppress_ids)] = -np.inf
-        if not without_timestamps:
-            apply_timestamp_rules(lg, tokens, sample_begin, tok)
+        apply_logit_filters(lg, tokens, sample_begin, tok, suppress_ids, without_timestamps, suppress_blank)
         top2 = lg.topk(2, dim=-1).values
         margins.append((top2[:, 0] - top2[:, 1]).numpy().copy())
         nxt = lg.argmax(dim=-1)
@@ -457,15 +496,11 @@ def beam_search_decode(model: OracleWhisper, xa: torch.Tensor, init_tokens: Sequ
     for i in range(sample_len):
         if i == 0:
             lg_all = model.decode_step(tokens, 0, cross, cache)
-            no_speech = lg_all[:, sot_index].float().softmax(-1)[:, tok.no_speech].clone()
+            no_speech = no_speech_probability(lg_all[:, sot_index], tok).clone()
             lg = lg_all[:, -1].clone()
         else:
             lg = model.decode_step(tokens[:, -1:], tokens.shape[1] - 1, cross, cache)[:, -1].clone()
-        if suppress_blank and tokens.shape[1] == sample_begin:
-            lg[:, [tok.blank, tok.eot]] = -np.inf
-        lg[:, list(suppress_ids)] = -np.inf
-        if not without_timestamps:
-            apply_timestamp_rules(lg, tokens, sample_begin, tok)
+        apply_logit_filters(lg, tokens, sample_begin, tok, suppress_ids, without_timestamps, suppress_blank)
         logprobs = F.log_softmax(lg.float(), dim=-1)
         next_tokens, source_indices, newly = [], [], []
         new_sums = sum_logprobs.clone()

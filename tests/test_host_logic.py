@@ -33,6 +33,56 @@ def test_dims_and_special_tokens():
         ck.dims_for("gigantic")
 
 
+def test_english_only_layout_and_suppress_tables():
+    """The three upstream vocabulary layouts and their non-speech suppress sets.  The tables must equal transformers'
+    generation defaults for the original checkpoints minus the control ids (hf:models/whisper/configuration_whisper.py:23-44)
+    -- the multilingual table for 51865 / 51866, the GPT-2 table only for English-only checkpoints."""
+    te = ck.special_tokens_for(51864)
+    assert (te.eot, te.sot, te.translate, te.transcribe, te.sot_lm, te.sot_prev, te.no_speech, te.no_timestamps, te.timestamp_begin) == \
+        (50256, 50257, 50357, 50358, 50359, 50360, 50361, 50362, 50363)
+    assert not ck.is_multilingual(51864) and ck.is_multilingual(51865) and ck.is_multilingual(51866)
+    with pytest.raises(ValueError):
+        ck.special_tokens_for(32000)
+    multi, en = ck.non_speech_suppress_ids(51865), ck.non_speech_suppress_ids(51864)
+    assert ck.non_speech_suppress_ids(51866) == multi and multi != en
+    assert {359, 503, 522, 50254} <= set(multi) and not {357, 366, 438} & set(multi)
+    cw = pytest.importorskip("transformers.models.whisper.configuration_whisper")
+    assert multi == [i for i in cw.NON_SPEECH_TOKENS_MULTI if i < ck.special_tokens_for(51865).eot]
+    assert en == [i for i in cw.NON_SPEECH_TOKENS if i < te.eot]
+    # upstream's "-1" set = the table + the six control tokens; HF's list holds four of them already
+    from whisper_amd.engine import default_suppress_ids
+    t = ck.special_tokens_for(51865)
+    full = default_suppress_ids(t, 51865)
+    assert set(cw.NON_SPEECH_TOKENS_MULTI) <= set(full)
+    assert set(full) - set(cw.NON_SPEECH_TOKENS_MULTI) == {t.translate, t.transcribe}
+    assert set(default_suppress_ids(te, 51864)) - set(cw.NON_SPEECH_TOKENS) == {te.translate, te.transcribe}
+
+
+def test_non_speech_tokens_from_a_vocabulary(tmp_path):
+    """Upstream's derivation rule on a toy tiktoken vocabulary: single-token symbols (alone or with a leading space) and the
+    first token of every musical-note character are suppressed, " -" and " '" always, plain "-" and "'" never."""
+    words = [b"\xe2\x99", b" -", b" '", b"[", b" [", b"((", b" ((", "♪".encode(), " ♪".encode(), b"<<", "♪♪".encode(), b"he"]
+    lines = [base64.b64encode(bytes([i])) + b" " + str(i).encode() for i in range(256)]
+    lines += [base64.b64encode(w) + b" " + str(256 + i).encode() for i, w in enumerate(words)]
+    vp = tmp_path / "sym.tiktoken"
+    vp.write_bytes(b"\n".join(lines) + b"\n")
+    tk = Tokenizer(51865, str(vp))
+    got = ck.non_speech_tokens_from_vocab(tk.encode)
+    ids = {w: 256 + i for i, w in enumerate(words)}
+    for w in (b" -", b" '", b"[", b" [", b"((", b" ((", "♪".encode(), " ♪".encode(), b"<<", "♪♪".encode()):
+        assert ids[w] in got, w
+    assert ids[b"he"] not in got and ord("-") not in got and ord("'") not in got
+    assert ord("#") in got and ord("{") in got                    # one-byte symbols are single tokens of the byte alphabet
+    assert ids[b"\xe2\x99"] in got                                # a note without a token of its own: its FIRST token
+    assert got == sorted(set(got))
+
+
+def test_beam_max_candidates_is_upstreams_round():
+    """max_candidates = round(beam_size * patience) with Python's round (ties to even, double arithmetic) -- the value the
+    host now computes once and hands to wx_decode_beam."""
+    assert [int(round(n * p)) for n, p in ((3, 1.5), (5, 1.5), (7, 1.5), (5, 1.7), (5, 1.0), (8, 2.0))] == [4, 8, 10, 8, 5, 16]
+
+
 def test_name_mapping_roundtrip_and_checkpoint_io(tmp_path):
     dims = ck.dims_for("micro")
     sd = ck.synthetic_state_dict(dims, seed=3)
@@ -153,7 +203,7 @@ def test_dropin_result_shaping(monkeypatch, tmp_path):
     monkeypatch.setattr(sr._tx, "transcribe", fake_transcribe)
     out = asyncio.run(sr.transcribe_audio(tmp_path / "a.wav", detailed=True))
     assert out == ("тестовый текст", 0.95, "ru") and isinstance(out[1], float)
-    assert seen["mode"] == "windows"                                                  # default decode_mode
+    assert seen["mode"] == "sequential"      # default decode_mode: upstream's own long-form loop, what the reference's call runs
     out = asyncio.run(sr.transcribe_audio(tmp_path / "a.wav", detailed=False))       # privacy branch still runs the model
     assert out == ("Voice authentication required for full transcription", 0.5, "ru") and len(calls) == 2
 

@@ -84,6 +84,75 @@ def test_greedy_rules_regression(name):
     assert len(set(lens)) > 1, "fixture should contain sequences that end at different steps"
 
 
+@pytest.mark.parametrize("n_vocab", [51865, 51866])
+def test_logit_filters_match_hf_processors(n_vocab):
+    """The oracle's decoding rules against transformers' own logits processors (hf:generation/logits_process.py:1816-2112)
+    on seeded logit rows and token histories that reach every branch of the timestamp rules, with and without the
+    "timestamp mass outweighs every text token" override: identical -inf masks, identical argmax, same log-probability;
+    the no-speech probability against WhisperNoSpeechDetection.  Fixture: tests/golden/hf_rules.npz (oracle/make_golden.py)."""
+    from oracle.make_golden import rule_cases, rule_logits
+    g = np.load(os.path.join(G, "hf_rules.npz"))
+    tok = ck.special_tokens_for(n_vocab)
+    sup = wo.suppress_token_ids(tok, ck.non_speech_suppress_ids(n_vocab))
+    prompt = [tok.sot, tok.lang(0), tok.transcribe]
+    cases = rule_cases(tok, n_vocab)
+    assert len(cases) == g[f"mask_{n_vocab}"].shape[0]
+    fired = 0
+    for ci, (h, boost) in enumerate(cases):
+        lg = rule_logits(1000 + ci, n_vocab, tok, boost)
+        row = lg[None].clone()
+        wo.apply_logit_filters(row, torch.tensor([prompt + h]), len(prompt), tok, sup, without_timestamps=False)
+        want = np.unpackbits(g[f"mask_{n_vocab}"][ci])[:n_vocab].astype(bool)
+        assert np.array_equal(torch.isinf(row[0]).numpy(), want), (ci, h, boost)
+        assert int(row[0].argmax()) == int(g[f"argmax_{n_vocab}"][ci])
+        lp = float(torch.log_softmax(row[0].float(), -1)[row[0].argmax()])
+        assert abs(lp - float(g[f"logprob_{n_vocab}"][ci])) < 1e-5
+        nsp = float(wo.no_speech_probability(lg[None], tok)[0])
+        assert abs(nsp - float(g[f"no_speech_{n_vocab}"][ci])) < 1e-9 + 1e-5 * nsp
+        fired += int(want[:tok.timestamp_begin].all())
+    assert 0 < fired < len(cases)            # the override (all text masked) is exercised, and so is its absence
+
+
+def test_greedy_loop_matches_hf_model_and_processors():
+    """oracle greedy_decode == a greedy loop built from the HF model forward and the HF logits processors (ragged EOT, with
+    and without timestamps): token ids equal, cumulative log-probabilities and no-speech probabilities within fp32 noise."""
+    g = np.load(os.path.join(G, "hf_greedy_micro.npz"))
+    dims = ck.dims_for("micro")
+    sd = ck.synthetic_state_dict(dims, seed=0, eot_boost=3.0)
+    tok = ck.special_tokens_for(dims.n_vocab)
+    om = wo.OracleWhisper(dims, sd)
+    sup = wo.suppress_token_ids(tok, ck.non_speech_suppress_ids(dims.n_vocab))
+    assert np.array_equal(np.asarray(sup, np.int32), g["suppress_ids"])
+    mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(s), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000] for s in range(4)])
+    with torch.no_grad():
+        xa = om.encode(mels)
+        for mode, wts, n_new in (("plain", True, 40), ("ts", False, 48)):
+            init = [int(i) for i in g[f"{mode}_init"]]
+            assert init == wo.initial_tokens(tok, 0, without_timestamps=wts)
+            r = wo.greedy_decode(om, xa, init, tok, sup, max_new_tokens=n_new, without_timestamps=wts)
+            assert r["margins"].min() > 1e-4
+            for b, t in enumerate(r["tokens"]):
+                assert t == [int(v) for v in g[f"{mode}_ids"][b] if v >= 0]
+            np.testing.assert_allclose(r["sum_logprobs"], g[f"{mode}_sum_logprobs"], rtol=1e-4, atol=1e-3)
+            np.testing.assert_allclose(r["no_speech_probs"], g[f"{mode}_no_speech"], rtol=1e-3)
+
+
+def test_bf16_emulation_is_a_small_perturbation_of_fp32():
+    """The bf16-emulating oracle (the yardstick of the GPU bf16 tolerance) differs from the fp32 oracle by bf16 rounding
+    noise only on smooth weights: more than fp32 noise, less than the smooth-weights bf16 bar of the GPU tests."""
+    dims = ck.dims_for("micro")
+    sd = ck.synthetic_state_dict(dims, seed=0, attn_gain=1.0)
+    f32, b16 = wo.OracleWhisper(dims, sd), wo.OracleWhisper(dims, sd, emulate_bf16=True)
+    mel = wo.log_mel_spectrogram(wo.varied_audio(2), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000][None]
+    toks = prefix_tokens(ck.special_tokens_for(dims.n_vocab))[:1]
+    with torch.no_grad():
+        a, b = f32.encode(mel), b16.encode(mel)
+        la, lb = f32.logits(toks, a), b16.logits(toks, b)
+    rel = lambda x, y: float((x - y).norm() / y.norm())
+    assert 1e-4 < rel(b, a) < 1.5e-2 and 1e-4 < rel(lb, la) < 1.5e-2
+    assert torch.equal(b, b.to(torch.bfloat16).float())          # the encoder output is stored in bf16
+
+
 def test_timestamp_rules_unit():
     tok = ck.special_tokens_for(51865)
     V = 51865

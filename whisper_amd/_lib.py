@@ -46,7 +46,7 @@ PROTOTYPES = {
     "wx_decode_greedy": (c_i32, [c_vp, c_i32, c_vp, ctypes.POINTER(WxDecodeOpts), c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_i32), c_vp]),
     "wx_decode_rows": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, ctypes.POINTER(WxDecodeOpts), ctypes.c_float, ctypes.c_uint32, c_vp, c_vp, c_vp,
                                c_vp, ctypes.POINTER(c_i32), c_vp]),
-    "wx_decode_beam": (c_i32, [c_vp, c_i32, c_i32, ctypes.c_float, c_vp, ctypes.POINTER(WxDecodeOpts), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+    "wx_decode_beam": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, ctypes.POINTER(WxDecodeOpts), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                ctypes.POINTER(c_i32), c_vp]),
     "wx_decoder_logits": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp]),
     "wx_get_profile": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),

@@ -91,11 +91,19 @@ class SpecialTokens:
 
 
 def special_tokens_for(n_vocab: int) -> SpecialTokens:
-    """51865-vocab models have 99 languages, the 51866-vocab (large-v3) family has 100."""
-    if n_vocab not in (51865, 51866):
-        raise ValueError(f"unsupported multilingual vocab size {n_vocab}")
-    n_langs = n_vocab - 51865 + 99
-    eot, sot = 50257, 50258
+    """Special-token ids of the three upstream vocabulary layouts [upstream-recall: ``whisper.tokenizer.get_encoding``
+    appends ``<|endoftext|>, <|startoftranscript|>, <|lang|> x num_languages, translate, transcribe, startoflm,
+    startofprev, nospeech, notimestamps, <|0.00|> ...`` to the BPE ranks]:
+
+    * 51865 -- multilingual (tiny ... large-v2): 50257 BPE ranks, 99 languages;
+    * 51866 -- large-v3 family: the same ranks, 100 languages (adds Cantonese), so every id from translate on is +1;
+    * 51864 -- English-only (``*.en``): the GPT-2 ranks (50256 of them), the same 99 language tokens in the table but
+      never used: the start sequence of these models is ``[sot]`` alone (``is_multilingual`` False)."""
+    if n_vocab not in (51864, 51865, 51866):
+        raise ValueError(f"unsupported Whisper vocabulary size {n_vocab} (known: 51864 English-only, 51865, 51866)")
+    n_langs = 100 if n_vocab == 51866 else 99
+    eot = 50256 if n_vocab == 51864 else 50257
+    sot = eot + 1
     translate = sot + 1 + n_langs
     return SpecialTokens(
         eot=eot, sot=sot, n_langs=n_langs, translate=translate, transcribe=translate + 1,
@@ -104,16 +112,55 @@ def special_tokens_for(n_vocab: int) -> SpecialTokens:
     )
 
 
-def non_speech_suppress_ids() -> list:
-    """A fixed stand-in for upstream's ``non_speech_tokens`` (the real list is derived from the BPE vocabulary,
-    which is not available offline).  Upstream's "-1" suppress set resolves to a few dozen punctuation and symbol
-    ids; the ids below are a deterministic list of the same size class used for *all* parity work in this repo.
-    The fixtures under tests/golden record the exact ids, so oracle and HIP path see identical masks."""
-    return [1, 2, 7, 8, 9, 10, 14, 25, 26, 27, 28, 29, 31, 58, 59, 60, 61, 62, 63, 90, 91, 92, 93,
-            357, 366, 438, 532, 685, 705, 796, 930, 1058, 1220, 1267, 1279, 1303, 1343, 1377, 1391, 1635,
-            1782, 1875, 2162, 2361, 2488, 3467, 4008, 4211, 4600, 4808, 5299, 5855, 6329, 7203, 9609, 9959,
-            10563, 10786, 11420, 11709, 11907, 13163, 13697, 13700, 14808, 15306, 16410, 16791, 17992, 19203,
-            19510, 20724, 22305, 22935, 27007, 30109, 30420, 33409, 34949, 40283, 40493, 40549, 47282, 49146]
+def is_multilingual(n_vocab: int) -> bool:
+    """Upstream ``ModelDimensions``-level rule: ``n_vocab >= 51865`` [upstream-recall]."""
+    return n_vocab >= 51865
+
+
+# Upstream ``Tokenizer.non_speech_tokens`` is derived from the BPE vocabulary (see ``non_speech_tokens_from_vocab``); the
+# vocabulary files ship inside the openai-whisper package and are not available offline, so the two resulting id sets are
+# tabulated here.  They are the ids below <|endoftext|> of transformers' generation defaults for the original checkpoints
+# (hf:models/whisper/configuration_whisper.py:34-44 ``NON_SPEECH_TOKENS_MULTI`` for ``multilingual.tiktoken``, :23-33
+# ``NON_SPEECH_TOKENS`` for ``gpt2.tiktoken``; the entries >= eot in those lists are the control tokens that
+# ``default_suppress_ids`` adds itself).  tests/test_host_logic.py checks both tables against transformers.
+_NON_SPEECH_MULTILINGUAL = (
+    1, 2, 7, 8, 9, 10, 14, 25, 26, 27, 28, 29, 31, 58, 59, 60, 61, 62, 63, 90, 91, 92, 93, 359, 503, 522, 542,
+    873, 893, 902, 918, 922, 931, 1350, 1853, 1982, 2460, 2627, 3246, 3253, 3268, 3536, 3846, 3961, 4183, 4667,
+    6585, 6647, 7273, 9061, 9383, 10428, 10929, 11938, 12033, 12331, 12562, 13793, 14157, 14635, 15265, 15618,
+    16553, 16604, 18362, 18956, 20075, 21675, 22520, 26130, 26161, 26435, 28279, 29464, 31650, 32302, 32470,
+    36865, 42863, 47425, 49870, 50254)
+_NON_SPEECH_ENGLISH = (
+    1, 2, 7, 8, 9, 10, 14, 25, 26, 27, 28, 29, 31, 58, 59, 60, 61, 62, 63, 90, 91, 92, 93,
+    357, 366, 438, 532, 685, 705, 796, 930, 1058, 1220, 1267, 1279, 1303, 1343, 1377, 1391, 1635,
+    1782, 1875, 2162, 2361, 2488, 3467, 4008, 4211, 4600, 4808, 5299, 5855, 6329, 7203, 9609, 9959,
+    10563, 10786, 11420, 11709, 11907, 13163, 13697, 13700, 14808, 15306, 16410, 16791, 17992, 19203,
+    19510, 20724, 22305, 22935, 27007, 30109, 30420, 33409, 34949, 40283, 40493, 40549, 47282, 49146)
+
+
+def non_speech_suppress_ids(n_vocab: int = 51865) -> list:
+    """Upstream's ``non_speech_tokens`` for the vocabulary the model was trained with: the multilingual table for the
+    51865 / 51866 layouts (both use ``multilingual.tiktoken``), the GPT-2 table for English-only checkpoints.  When a
+    vocabulary file is configured, ``transcribe.configure`` derives the set from it instead
+    (``non_speech_tokens_from_vocab``) and passes it to the engine."""
+    return list(_NON_SPEECH_MULTILINGUAL if is_multilingual(n_vocab) else _NON_SPEECH_ENGLISH)
+
+
+def non_speech_tokens_from_vocab(encode) -> list:
+    """Upstream ``Tokenizer.non_speech_tokens`` [upstream-recall] on a loaded vocabulary: ``encode(str) -> ids``.
+
+    The ids of the annotation symbols that must not be sampled ("♪♪♪", "( SPEAKING FOREIGN LANGUAGE )", "[DAVID]" ...):
+    every symbol of the list below, alone and with a leading space, is encoded; a one-token encoding is suppressed, and
+    for the musical-note characters (multi-byte, possibly split over tokens) the first token is; " -" and " '" are
+    always included, while plain hyphens and apostrophes inside words stay allowed."""
+    symbols = list("\"#()*+/:;<=>@[\\]^_`{|}~「」『』")
+    symbols += "<< >> <<< >>> -- --- -( -[ (' (\" (( )) ((( ))) [[ ]] {{ }} ♪♪ ♪♪♪".split()
+    miscellaneous = set("♩♪♫♬♭♮♯")
+    result = {encode(" -")[0], encode(" '")[0]}
+    for symbol in symbols + sorted(miscellaneous):
+        for tokens in (encode(symbol), encode(" " + symbol)):
+            if len(tokens) == 1 or symbol in miscellaneous:
+                result.add(tokens[0])
+    return sorted(int(i) for i in result)
 
 
 def sinusoids(length: int, channels: int, max_timescale: float = 10000.0) -> torch.Tensor:

@@ -326,8 +326,12 @@ int wx_set_suppress_tokens(wx_engine* e, const int32_t* h_ids, int32_t n) {
     for (int i = 0; i < n; ++i) if (h_ids[i] < 0 || h_ids[i] >= e->cfg.n_vocab) return fail(WX_ERR_INVALID, "suppress id out of range");
     e->suppress_h.assign(h_ids, h_ids + n);
     if (e->finalized) {
-        std::vector<uint8_t> m(e->cfg.n_vocab, 0);
+        // the mask is read by every sampler launch, the captured step graph included: wait for whatever the engine's
+        // device still has in flight before it changes (the caller must not change it WHILE a decode call is running)
+        DeviceScope dev_scope(e);
+        std::vector<uint8_t> m(e->vocab_pad, 0);
         for (int id : e->suppress_h) m[id] = 1;
+        HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(e->suppress, m.data(), m.size(), hipMemcpyHostToDevice));
     }
     return WX_OK;
@@ -1034,7 +1038,7 @@ int wx_decode_rows(wx_engine* e, int32_t B, const int32_t* h_prompts, const int3
                             d_no_speech_prob, h_steps, stream);
 }
 
-int wx_decode_beam(wx_engine* e, int32_t B, int32_t beam_size, float patience, const int32_t* h_prompt, const wx_decode_opts* opts,
+int wx_decode_beam(wx_engine* e, int32_t B, int32_t beam_size, int32_t max_candidates, const int32_t* h_prompt, const wx_decode_opts* opts,
                    int32_t* d_fin_tokens, float* d_fin_sum_logprob, int32_t* d_fin_count, int32_t* d_beam_tokens,
                    float* d_beam_sum_logprob, float* d_no_speech_prob, int32_t* h_steps, void* stream) {
     if (!e || !e->finalized) return fail(WX_ERR_STATE, "engine not finalized");
@@ -1043,8 +1047,11 @@ int wx_decode_beam(wx_engine* e, int32_t B, int32_t beam_size, float patience, c
         return fail(WX_ERR_INVALID, "null argument");
     const wx_config& c = e->cfg;
     if (beam_size < 1 || beam_size > 8) return fail(WX_ERR_INVALID, "beam_size must be 1..8");
-    if (!(patience >= 1.0f) || patience > 2.0f) return fail(WX_ERR_INVALID, "patience must be in [1, 2]");
-    const int n = beam_size, R = B * n, maxc = (int)lroundf(n * patience);
+    // the caller computes upstream's round(beam_size * patience) (Python: double arithmetic, round-half-even) and sizes its
+    // finished-list buffers with it; recomputing it here in float would disagree at ties (beam 5, patience 1.7 -> 8 vs 9)
+    if (max_candidates < beam_size || max_candidates > 2 * beam_size)
+        return fail(WX_ERR_INVALID, "max_candidates must be in [beam_size, 2 * beam_size] (patience in [1, 2])");
+    const int n = beam_size, R = B * n, maxc = max_candidates;
     if (B <= 0 || B > e->encoded_B) return fail(WX_ERR_INVALID, "decode batch exceeds the last wx_encode batch");
     if (R > c.max_batch) return fail(WX_ERR_INVALID, "windows x beam_size exceeds max_batch");
     wx_decode_opts o = *opts;

@@ -105,9 +105,23 @@ def gather_results(local: Dict[str, object], n_local_max: int, n_ctx: int, eot: 
     return {"tokens": out_t, "sum_logprobs": out_s, "no_speech_probs": out_n}
 
 
-def transcribe_sharded(engine, audio: np.ndarray, prompt: Sequence[int], group=None, **decode_kw) -> Dict[str, object]:
+def broadcast_int(value: int, device, src: int = 0, group=None) -> int:
+    """One int32 from rank ``src`` to every rank (the detected language: 4 bytes)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return int(value)
+    host = dist.get_backend(group) == "gloo"
+    t = torch.tensor([int(value)], dtype=torch.int32, device="cpu" if host else device)
+    dist.broadcast(t, src=src, group=group)
+    return int(t.item())
+
+
+def transcribe_sharded(engine, audio: np.ndarray, prompt, group=None, **decode_kw) -> Dict[str, object]:
     """Every rank passes the same host ``audio``; each uploads and processes only its own windows.  All ranks return
-    the full, window-ordered result."""
+    the full, window-ordered result.
+
+    ``prompt``: the initial ids shared by all windows, or a callable ``language_index -> ids`` -- then the language is
+    detected first, as upstream does, on the first 30 s of the WHOLE-FILE mel (clamped with the whole-file maximum, which is
+    known after the MAX all-reduce): rank 0 owns window 0, detects, and broadcasts the index (one more 4-byte exchange)."""
     rank, world = rank_world(group)
     is_pcm16 = isinstance(audio, np.ndarray) and audio.dtype == np.int16     # raw samples: converted on the device
     audio = np.ascontiguousarray(audio if is_pcm16 else np.asarray(audio, dtype=np.float32))
@@ -119,6 +133,11 @@ def transcribe_sharded(engine, audio: np.ndarray, prompt: Sequence[int], group=N
     pcm_local = engine.pcm16_to_f32(local) if is_pcm16 else torch.from_numpy(local).to(engine.torch_device)
     mel = sharded_mel(engine, pcm_local, s_lo, n_file, w_lo, w_hi, group)
     content = n_file // HOP_LENGTH
+    language_index = None
+    if callable(prompt):
+        language_index = engine.detect_language(mel, content) if rank == 0 and w_hi > w_lo else 0
+        language_index = broadcast_int(language_index, engine.torch_device, 0, group)
+        prompt = prompt(language_index)
     if w_hi > w_lo:
         local = engine.transcribe_mel(mel, content - w_lo * N_FRAMES, 0, w_hi - w_lo, prompt, **decode_kw)
     else:
@@ -128,4 +147,5 @@ def transcribe_sharded(engine, audio: np.ndarray, prompt: Sequence[int], group=N
     out["n_windows"] = nw
     out["local_windows"] = (w_lo, w_hi)
     out["steps"] = local.get("steps", 0)
+    out["language_index"] = language_index
     return out

@@ -15,14 +15,16 @@ import torch
 
 from . import _lib
 from .audio import HOP_LENGTH, N_FRAMES, N_SAMPLES, n_windows, slaney_mel_filterbank
-from .checkpoint import ModelDims, SpecialTokens, non_speech_suppress_ids, special_tokens_for
+from .checkpoint import ModelDims, SpecialTokens, is_multilingual, non_speech_suppress_ids, special_tokens_for
 
 PRECISIONS = {"fp32": 0, "bf16": 1}
 
 
-def default_suppress_ids(tok: SpecialTokens) -> List[int]:
-    """Upstream ``_get_suppress_tokens`` for ``suppress_tokens="-1"``: non-speech symbols + task/control tokens."""
-    ids = list(non_speech_suppress_ids()) + [tok.transcribe, tok.translate, tok.sot, tok.sot_prev, tok.sot_lm, tok.no_speech]
+def default_suppress_ids(tok: SpecialTokens, n_vocab: int = 51865, non_speech: Optional[Sequence[int]] = None) -> List[int]:
+    """Upstream ``_get_suppress_tokens`` for ``suppress_tokens="-1"``: the vocabulary's non-speech symbols (derived from a
+    loaded vocabulary by the caller, else the table of ``checkpoint.non_speech_suppress_ids``) + task/control tokens."""
+    ns = non_speech_suppress_ids(n_vocab) if non_speech is None else non_speech
+    ids = list(ns) + [tok.transcribe, tok.translate, tok.sot, tok.sot_prev, tok.sot_lm, tok.no_speech]
     return sorted(set(int(i) for i in ids))
 
 
@@ -66,7 +68,7 @@ class WhisperEngine:
             if fb.shape != (dims.n_mels, 201):
                 raise ValueError(f"mel_filters must be [{dims.n_mels}, 201]")
             _lib.check(self.lib.wx_set_mel_filters(self.handle, fb.ctypes.data_as(ctypes.c_void_p)), "wx_set_mel_filters")
-            self.suppress_ids = list(default_suppress_ids(t) if suppress_ids is None else suppress_ids)
+            self.suppress_ids = list(default_suppress_ids(t, dims.n_vocab) if suppress_ids is None else suppress_ids)
             sup = np.asarray(self.suppress_ids, np.int32)
             _lib.check(self.lib.wx_set_suppress_tokens(self.handle, sup.ctypes.data_as(ctypes.c_void_p), len(sup)),
                        "wx_set_suppress_tokens")
@@ -249,7 +251,7 @@ class WhisperEngine:
             max_initial_timestamp_index=int(max_initial_timestamp_index), use_graph=int(use_graph),
             check_interval=int(check_interval), profile_stride=0)
         dev, n, ctx = self.torch_device, int(beam_size), self.dims.n_text_ctx + 1   # ids per row
-        maxc = int(round(n * patience))
+        maxc = int(round(n * patience))     # upstream's rule, computed once here: it sizes fin_t / fin_s and goes to the device
         fin_t = torch.empty((B, maxc, ctx), dtype=torch.int32, device=dev)
         fin_s = torch.empty((B, maxc), dtype=torch.float32, device=dev)
         fin_c = torch.empty(B, dtype=torch.int32, device=dev)
@@ -258,7 +260,7 @@ class WhisperEngine:
         nsp = torch.empty(B, dtype=torch.float32, device=dev)
         steps = ctypes.c_int32(0)
         h_prompt = (ctypes.c_int32 * len(prompt))(*prompt)
-        _lib.check(self.lib.wx_decode_beam(self.handle, B, n, ctypes.c_float(patience), h_prompt, ctypes.byref(opts), _ptr(fin_t),
+        _lib.check(self.lib.wx_decode_beam(self.handle, B, n, maxc, h_prompt, ctypes.byref(opts), _ptr(fin_t),
                                            _ptr(fin_s), _ptr(fin_c), _ptr(beam_t), _ptr(beam_s), _ptr(nsp), ctypes.byref(steps),
                                            self._stream()), "wx_decode_beam")
         fin_t, fin_s, fin_c = fin_t.cpu().numpy(), fin_s.cpu().numpy(), fin_c.cpu().numpy()
@@ -299,11 +301,25 @@ class WhisperEngine:
         _lib.check(self.lib.wx_decoder_logits(self.handle, B, _ptr(tokens), n, _ptr(out), self._stream()), "wx_decoder_logits")
         return out
 
+    def detect_language(self, mel: torch.Tensor, n_content_frames: int) -> int:
+        """Upstream ``detect_language`` on the first 30 s segment of a (whole-file, globally clamped) mel ``[n_mels, ld]``:
+        one decoder step on ``[sot]``, argmax over the language tokens (hf:models/whisper/generation_whisper.py:1610-1673).
+        English-only checkpoints have no language tokens to choose from: upstream's ``transcribe`` fixes "en" for them."""
+        if not is_multilingual(self.dims.n_vocab):
+            return 0
+        self.encode(mel, N_FRAMES, mel.stride(0), n_content_frames, 1)
+        tok = self.tok
+        logits = self.decoder_logits(torch.tensor([[tok.sot]], dtype=torch.int32))[0, 0]
+        return int(torch.argmax(logits[tok.sot + 1: tok.sot + 1 + tok.n_langs]).item())
+
     # -- whole path ---------------------------------------------------------------------------------------
     def initial_tokens(self, language_index: int = 0, task: str = "transcribe", without_timestamps: bool = True,
                        prompt_ids: Optional[Sequence[int]] = None) -> List[int]:
         t = self.tok
-        seq = [t.sot, t.lang(language_index), t.transcribe if task == "transcribe" else t.translate]
+        if is_multilingual(self.dims.n_vocab):
+            seq = [t.sot, t.lang(language_index), t.transcribe if task == "transcribe" else t.translate]
+        else:
+            seq = [t.sot]           # English-only checkpoints: upstream's sot_sequence carries no language / task token
         if without_timestamps:
             seq.append(t.no_timestamps)
         if prompt_ids:

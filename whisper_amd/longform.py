@@ -92,7 +92,7 @@ def _split_segments(tokens: List[int], tb: int, eot: int, seek: int, segment_siz
     return out, nxt
 
 
-def transcribe_sequential(engine, audios: Sequence, decode_text: Callable[[Sequence[int]], str], language_index: int = 0,
+def transcribe_sequential(engine, audios: Sequence, decode_text: Callable[[Sequence[int]], str], language_index: Optional[int] = 0,
                           initial_prompts: Optional[Sequence[Optional[Sequence[int]]]] = None,
                           temperatures: Sequence[float] = (0.0, 0.2, 0.4, 0.6, 0.8, 1.0),
                           compression_ratio_threshold: Optional[float] = 2.4, logprob_threshold: Optional[float] = -1.0,
@@ -100,7 +100,8 @@ def transcribe_sequential(engine, audios: Sequence, decode_text: Callable[[Seque
                           max_new_tokens: int = 0, seed: int = 0, use_graph: bool = True) -> List[Dict[str, object]]:
     """``audios``: float32 16 kHz arrays / tensors (or int16 PCM arrays), one per file.  Returns one dict per file:
     ``segments`` (seek, start, end, tokens, text, temperature, avg_logprob, compression_ratio, no_speech_prob), ``tokens``,
-    ``text``, ``windows`` (decoded windows, skipped ones included)."""
+    ``text``, ``windows`` (decoded windows, skipped ones included), ``language_index``.  ``language_index=None`` detects
+    the language of every file on the first 30 s of its whole-file mel, as upstream does."""
     tok = engine.tok
     dev = engine.torch_device
     n_mels = engine.dims.n_mels
@@ -112,7 +113,9 @@ def transcribe_sequential(engine, audios: Sequence, decode_text: Callable[[Seque
             pcm = torch.as_tensor(a).to(dev, torch.float32).contiguous()
         mel = engine.log_mel(pcm)                                   # whole file + 30 s of padding, whole-file clamp
         ip = (initial_prompts[i] if initial_prompts else None) or []
-        states.append(_FileState(mel, mel.shape[-1] - N_FRAMES, ip))
+        st = _FileState(mel, mel.shape[-1] - N_FRAMES, ip)
+        st.language_index = engine.detect_language(mel, st.content_frames) if language_index is None else int(language_index)
+        states.append(st)
     batch = torch.zeros((engine.max_batch, n_mels, N_FRAMES), dtype=torch.float32, device=dev)
     while True:
         active = [s for s in states if not s.done][: engine.max_batch]
@@ -126,7 +129,7 @@ def transcribe_sequential(engine, audios: Sequence, decode_text: Callable[[Seque
             batch[b, :, :size] = s.mel[:, s.seek:s.seek + size]
             sizes.append(size)
         engine.encode(batch, n_mels * N_FRAMES, N_FRAMES, B * N_FRAMES, B)
-        prompts = [engine.initial_tokens(language_index, without_timestamps=False, prompt_ids=s.all_tokens[s.prompt_reset_since:])
+        prompts = [engine.initial_tokens(s.language_index, without_timestamps=False, prompt_ids=s.all_tokens[s.prompt_reset_since:])
                    for s in active]
         result: List[Optional[Dict[str, object]]] = [None] * B
         pending = list(range(B))
@@ -175,5 +178,6 @@ def transcribe_sequential(engine, audios: Sequence, decode_text: Callable[[Seque
     out = []
     for s in states:
         toks = s.all_tokens[s.n_initial:]
-        out.append({"segments": s.segments, "tokens": toks, "text": decode_text([t for t in toks if t < tok.eot]), "windows": s.windows})
+        out.append({"segments": s.segments, "tokens": toks, "text": decode_text([t for t in toks if t < tok.eot]), "windows": s.windows,
+                    "language_index": s.language_index})
     return out

@@ -12,7 +12,9 @@ before ``app.transcription.openai_whisper`` is imported (it binds ``transcribe_a
 Build-specific settings live in a NEW config section so existing keys keep their meaning:
     whisper_amd: {checkpoint: /path/model.pt, vocab: /path/multilingual.tiktoken, precision: bf16, max_batch: 16,
                   allow_synthetic_weights: false, confidence_mode: reference,
-                  decode_mode: windows | sequential, beam_size: null}
+                  decode_mode: sequential | windows, beam_size: null}
+``decode_mode`` defaults to ``sequential``: upstream's own long-form loop with upstream's defaults, which is what the
+reference's call runs.  ``windows`` is the opt-in throughput mode (independent 30 s windows, batched, sharded over ranks).
 """
 from __future__ import annotations
 
@@ -93,13 +95,15 @@ async def transcribe_audio(audio_path: Path, detailed: bool = True) -> Tuple[str
     if whisper_model is None:
         raise RuntimeError("Whisper model not initialized")
     try:
-        # decode_mode "windows" (default): independent 30 s windows, batched and sharded; "sequential": upstream's own
-        # long-form loop with upstream's defaults (timestamps, previous-text prompt, temperature fallback) -- what the
-        # reference's call really runs (ref:speech_recognition.py:48-52 passes only language, task, fp16)
+        # decode_mode "sequential" (default): upstream's own long-form loop with upstream's defaults (timestamps,
+        # previous-text prompt, timestamp-driven seek, no-speech skip, temperature fallback) -- what the reference's call
+        # runs (ref:speech_recognition.py:48-52 passes only language, task, fp16).  "windows": independent 30 s windows,
+        # batched and sharded across ranks (the throughput mode; a declared divergence)
         kw = {}
-        if _AMD.get("beam_size"):
+        mode = str(_AMD.get("decode_mode", "sequential"))
+        if _AMD.get("beam_size") and mode == "windows":
             kw["beam_size"] = int(_AMD["beam_size"])
-        result = _tx.transcribe(str(audio_path), language=LANGUAGE, mode=str(_AMD.get("decode_mode", "windows")), **kw)
+        result = _tx.transcribe(str(audio_path), language=LANGUAGE, mode=mode, **kw)
         text = result["text"].strip()
         language = result.get("language", "unknown")
         confidence = float(result.get("confidence", 0.0))

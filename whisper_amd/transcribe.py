@@ -50,9 +50,15 @@ def configure(model: str = "base", checkpoint: Optional[str] = None, vocab: Opti
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0"))
     close()
-    eng = WhisperEngine(dims, sd, precision=precision, max_batch=max_batch, device=device)
+    tokenizer = Tokenizer(dims.n_vocab, vocab)
+    suppress_ids = None
+    if tokenizer.has_vocab:
+        # upstream derives the non-speech suppress set from the vocabulary it loads (Tokenizer.non_speech_tokens); so do we
+        from .engine import default_suppress_ids
+        suppress_ids = default_suppress_ids(tokenizer.special, dims.n_vocab, ck.non_speech_tokens_from_vocab(tokenizer.encode))
+    eng = WhisperEngine(dims, sd, precision=precision, max_batch=max_batch, device=device, suppress_ids=suppress_ids)
     _STATE["engine"] = eng
-    _STATE["tokenizer"] = Tokenizer(dims.n_vocab, vocab)
+    _STATE["tokenizer"] = tokenizer
     _STATE["settings"] = {"model": model, "confidence_mode": confidence_mode}
     return eng
 
@@ -94,16 +100,6 @@ def _load_audio(audio: Union[str, Path, np.ndarray, torch.Tensor]) -> np.ndarray
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
-def detect_language(engine, mel: torch.Tensor, n_content_frames: int) -> int:
-    """Upstream ``detect_language`` on the first window: one decoder step on ``[sot]``, argmax over the language
-    tokens (hf:models/whisper/generation_whisper.py:1610-1673)."""
-    engine.encode(mel, N_FRAMES, mel.stride(0), n_content_frames, 1)
-    tok = engine.tok
-    logits = engine.decoder_logits(torch.tensor([[tok.sot]], dtype=torch.int32))[0, 0]
-    langs = logits[tok.sot + 1: tok.sot + 1 + tok.n_langs]
-    return int(torch.argmax(langs).item())
-
-
 def _prompt_ids(prompt, tokenizer: Tokenizer) -> Optional[List[int]]:
     if prompt is None or (isinstance(prompt, str) and not prompt.strip()):
         return None
@@ -138,34 +134,29 @@ def transcribe(audio, language: Optional[str] = None, prompt: Union[None, str, S
     if pcm_host.shape[0] == 0:
         return {"text": "", "confidence": 0.0, "chunks_processed": 0, "language": language or "en", "tokens": [],
                 "avg_logprob": [], "no_speech_prob": []}
-    rank, world = wdist.rank_world()
-    n_file = int(pcm_host.shape[0])
-    if language is None:
-        # language id needs the first window only; every rank computes it (identical result, no exchange needed)
-        head = pcm_host[: min(n_file, N_SAMPLES)]
-        first = eng.pcm16_to_f32(head) if head.dtype == np.int16 else torch.from_numpy(head).to(eng.torch_device)
-        mel0 = eng.log_mel(first)
-        lang_idx = detect_language(eng, mel0, min(n_file, N_SAMPLES) // 160)
-    else:
-        lang_idx = language_index(language, eng.dims.n_vocab)
+    cmode = (_STATE["settings"] or {}).get("confidence_mode", "reference")
+    lang_idx = None if language is None else language_index(language, eng.dims.n_vocab)
     if mode == "sequential":
         from .longform import transcribe_sequential
         r = transcribe_sequential(eng, [pcm_host], tokenizer.decode, language_index=lang_idx,
                                   initial_prompts=[_prompt_ids(prompt, tokenizer)], **decode_kw)[0]
         lps = [sg["avg_logprob"] for sg in r["segments"]]
-        cmode = (_STATE["settings"] or {}).get("confidence_mode", "reference")
         conf = 0.0 if cmode == "reference" or not lps else float(math.exp(sum(lps) / len(lps)))
         return {"text": r["text"].strip(), "confidence": conf, "chunks_processed": int(r["windows"]),
-                "language": LANGUAGE_CODES[lang_idx], "tokens": r["tokens"], "segments": r["segments"],
+                "language": LANGUAGE_CODES[r["language_index"]], "tokens": r["tokens"], "segments": r["segments"],
                 "avg_logprob": lps, "no_speech_prob": [sg["no_speech_prob"] for sg in r["segments"]]}
     if mode != "windows":
         raise ValueError("mode must be 'windows' or 'sequential'")
-    init = eng.initial_tokens(lang_idx, prompt_ids=_prompt_ids(prompt, tokenizer))
+    # language None: detected inside the sharded pass, on the first 30 s of the whole-file mel (upstream's rule; one rank
+    # detects, the index is broadcast)
+    pids = _prompt_ids(prompt, tokenizer)
+    init = (lambda li: eng.initial_tokens(li, prompt_ids=pids)) if lang_idx is None else eng.initial_tokens(lang_idx, prompt_ids=pids)
     res = wdist.transcribe_sharded(eng, pcm_host, init, **decode_kw)
+    if lang_idx is None:
+        lang_idx = int(res["language_index"])
     texts = [tokenizer.decode(t) for t in res["tokens"]]
     avg_lp = [float(s) / (len(t) + 1) for s, t in zip(res["sum_logprobs"], res["tokens"])]
-    mode = (_STATE["settings"] or {}).get("confidence_mode", "reference")
-    confidence = 0.0 if mode == "reference" or not avg_lp else float(math.exp(sum(avg_lp) / len(avg_lp)))
+    confidence = 0.0 if cmode == "reference" or not avg_lp else float(math.exp(sum(avg_lp) / len(avg_lp)))
     return {
         "text": "".join(texts).strip(), "confidence": confidence, "chunks_processed": int(res["n_windows"]),
         "language": LANGUAGE_CODES[lang_idx], "tokens": res["tokens"], "avg_logprob": avg_lp,
