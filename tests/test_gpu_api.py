@@ -95,11 +95,20 @@ def test_transcribe_contract_and_dropin(tmp_path, monkeypatch):
         # language auto-detection = argmax over the language tokens of one decoder step on [sot]
         om = wo.OracleWhisper(eng.dims, ck.synthetic_state_dict(eng.dims, 0))
         with torch.no_grad():
-            mel = wo.log_mel_spectrogram(audio[:wo.N_SAMPLES], eng.dims.n_mels, padding=wo.N_SAMPLES)[:, :3000]
+            # upstream detects on the first 30 s of the WHOLE-FILE mel (clamped with the whole-file maximum)
+            mel = wo.log_mel_spectrogram(audio, eng.dims.n_mels, padding=wo.N_SAMPLES)[:, :3000]
             lg = om.logits(torch.tensor([[eng.tok.sot]]), om.encode(mel[None]))[0, 0]
         want = int(lg[eng.tok.sot + 1: eng.tok.sot + 1 + eng.tok.n_langs].argmax())
         from whisper_amd.tokenizer import LANGUAGE_CODES
         assert tx.transcribe(audio, max_new_tokens=2)["language"] == LANGUAGE_CODES[want]
+        assert tx.transcribe(audio, mode="sequential", max_new_tokens=2, temperatures=(0.0,))["language"] == LANGUAGE_CODES[want]
+        # ... also when the loud part of the file comes after the first window (the clamp of window 0 is the file's)
+        late = np.concatenate([audio[:wo.N_SAMPLES] * 0.002, audio[wo.N_SAMPLES:]]).astype(np.float32)
+        with torch.no_grad():
+            mel = wo.log_mel_spectrogram(late, eng.dims.n_mels, padding=wo.N_SAMPLES)[:, :3000]
+            lg = om.logits(torch.tensor([[eng.tok.sot]]), om.encode(mel[None]))[0, 0]
+        want_late = int(lg[eng.tok.sot + 1: eng.tok.sot + 1 + eng.tok.n_langs].argmax())
+        assert tx.transcribe(late, max_new_tokens=2)["language"] == LANGUAGE_CODES[want_late]
         # the drop-in module on top of the same engine
         import whisper_amd.speech_recognition as sr
         monkeypatch.setattr(sr, "whisper_model", eng)

@@ -301,6 +301,28 @@ def test_beam_search_matches_oracle_fp32(models, name, beam, boost, use_graph):
     assert [t[b, len(init):len(init) + int(n[b])].tolist() for b in range(3)] == g["tokens"]
 
 
+@pytest.mark.parametrize("beam,patience", [(3, 1.5), (5, 1.5), (5, 1.7)])
+def test_beam_search_patience_fp32(models, beam, patience):
+    """patience != 1: max_candidates = round(beam * patience) with upstream's rounding (3 x 1.5 -> 4, 5 x 1.5 -> 8 and
+    5 x 1.7 = 8.5 -> 8: ties to even) sizes the finished lists on both sides of the C-ABI; ids, candidates and scores equal
+    the oracle's."""
+    dims, sd, eng = models("micro", "fp32", max_batch=2 * beam, eot_boost=6.0)
+    om = wo.OracleWhisper(dims, sd)
+    tok = eng.tok
+    mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(s), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000] for s in (5, 6)])
+    init = wo.initial_tokens(tok, 0)
+    with torch.no_grad():
+        ref = wo.beam_search_decode(om, om.encode(mels), init, tok, wo.suppress_token_ids(tok, ck.non_speech_suppress_ids()),
+                                    beam_size=beam, patience=patience, max_new_tokens=32)
+    eng.encode_windows(mels)
+    got = eng.decode_beam(2, init, beam_size=beam, patience=patience, max_new_tokens=32, check_interval=1)
+    assert got["tokens"] == ref["tokens"] and got["steps"] == ref["steps"]
+    for b in range(2):
+        assert [c[0] for c in got["candidates"][b]] == [c[0] for c in ref["candidates"][b]]
+        assert len(got["candidates"][b]) <= max(beam, int(round(beam * patience)))
+        np.testing.assert_allclose([c[1] for c in got["candidates"][b]], [c[1] for c in ref["candidates"][b]], rtol=1e-4, atol=2e-3)
+
+
 def test_beam_search_at_the_text_context_limit_fp32(models):
     """Beam search from a maximum-length previous-text prompt with no EOT in sight: like upstream, the beams take their last
     step from position n_text_ctx - 1 and end with n_text_ctx + 1 ids; finalize() then ranks the live beams."""
