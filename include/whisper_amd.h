@@ -107,6 +107,18 @@ int wx_mel_stage1(wx_engine* e, const float* d_pcm, int64_t pcm_offset, int64_t 
                   float* d_max, void* stream);
 int wx_mel_stage2(wx_engine* e, float* d_logmel, int64_t ld, int64_t n_frames, const float* d_max, void* stream);
 
+/* NO COUNTERPART IN THE REFERENCE.  For callers that cannot allocate device memory or hand over a workspace: code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc.  Whole-buffer log-mel (what wx_mel_reset_max +
+ * wx_mel_stage1 + wx_mel_stage2 compute for frame0 = 0, pcm_offset = 0: (n_samples + padding) / 160 frames, clamp against
+ * the buffer's own maximum) with NO workspace argument: the maximum and the per-workgroup partial maxima live in a 256 KiB
+ * file-scope device array of the library (one copy per GPU, held until the process ends).  The call allocates nothing --
+ * no hipMalloc / hipFree, no host containers -- and launches three kernels on `stream`.  Limits: at most
+ * (65536 - 64) * 8 = 523776 frames (87 min of audio including padding), rejected with WX_ERR_INVALID beyond that.  Every
+ * call on one GPU shares that GPU's array: calls that overlap on one GPU (two streams, two engines on the same device)
+ * race; serialise them.  Bit-identical to the three-call form (max is order-independent). */
+int wx_log_mel_static(wx_engine* e, const float* d_pcm, int64_t n_samples, int64_t padding, float* d_logmel, int64_t ld,
+                      void* stream);
+
 /* replaces AudioEncoder.forward + the per-layer cross-attention K/V projection (inside model.transcribe,
  * ref:speech_recognition.py:55).  d_mel: fp32 features, element (w, m, t) at d_mel[w*win_stride + m*row_stride + t]
  * (contiguous windows: win_stride = n_mels*3000, row_stride = 3000; a whole-file mel [n_mels][ld]: win_stride =

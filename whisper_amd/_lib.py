@@ -41,6 +41,7 @@ PROTOTYPES = {
     "wx_mel_reset_max": (c_i32, [c_vp, c_vp, c_vp]),
     "wx_mel_stage1": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "wx_mel_stage2": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
+    "wx_log_mel_static": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
     "wx_encode": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "wx_get_encoder_output": (c_i32, [c_vp, c_i32, c_vp, c_vp]),
     "wx_decode_greedy": (c_i32, [c_vp, c_i32, c_vp, ctypes.POINTER(WxDecodeOpts), c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_i32), c_vp]),

@@ -110,7 +110,11 @@ struct MelTables {                       // device tables built at wx_finalize
 };
 int launch_mel_stage1(const MelTables& t, const float* pcm, int64_t pcm_offset, int64_t n_valid, int64_t n_file,
                       int64_t n_total, int64_t frame0, int64_t n_frames, float* out, int64_t ld, float* d_max,
-                      hipStream_t st);
+                      hipStream_t st, float* block_max = nullptr);
+// block_max != nullptr: every workgroup stores its maximum to block_max[blockIdx] (mel_stage1_blocks(n_frames) floats)
+// instead of folding it into *d_max; launch_mel_fold_block_max reduces them to one float
+int mel_stage1_blocks(int64_t n_frames);
+int launch_mel_fold_block_max(const float* part, int n, float* out, hipStream_t st);
 int launch_mel_stage2(float* x, int64_t ld, int n_mels, int64_t n_frames, const float* d_max, hipStream_t st);
 int launch_fill_f32(float* p, float v, int64_t n, hipStream_t st);
 int launch_pcm16_to_f32(const int16_t* in, float* out, int64_t n, hipStream_t st);   // x / 32768

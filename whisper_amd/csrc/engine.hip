@@ -84,6 +84,7 @@ struct wx_engine {
     uint32_t* dyn = nullptr;                                 // {temperature bits, seed, sample_len} read by the sampler
     float *sum_logprob = nullptr, *no_speech = nullptr, *partial = nullptr, *gpartial = nullptr, *samp_part = nullptr;
     int32_t* h_pinned = nullptr;
+    float* static_scratch = nullptr;                         // this device's address of the file-scope `scratch` array (wx_log_mel_static)
     float* rs_taps = nullptr;                                // resampler taps (wx_resample_pcm16), RS_MAX_TAPS floats
     int encoded_B = 0;
     // beam search state (rows = windows x beams <= max_batch)
@@ -250,6 +251,23 @@ struct StreamScope {   // graph capture needs a real stream: route NULL-stream c
 
 }  // namespace
 
+// ---- the allocation-free entry point (include/whisper_amd.h: wx_log_mel_static) ------------------------------------------
+// Its only device memory beyond input and output is this file-scope array: slot 0 holds the buffer's maximum, slots
+// WX_STATIC_HEAD ... the per-workgroup maxima of the stage-1 launch.  Every GPU the library runs on holds its own copy at
+// its own address until the process ends (256 KiB).  `scratch` itself is a host-side stand-in for the symbol, NOT a device
+// address: host code only ever uses the per-device pointer that hipGetSymbolAddress returned (resolved in wx_create with
+// the engine's device current and kept in the engine).
+constexpr int WX_STATIC_FLOATS = 65536, WX_STATIC_HEAD = 64;
+static __device__ __align__(256) float scratch[WX_STATIC_FLOATS];
+
+static int resolve_static_scratch(wx_engine* e) {       // caller holds a DeviceScope on e
+    float* ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) return fail(WX_ERR_HIP, "hipGetSymbolAddress(scratch) returned a null address");
+    e->static_scratch = ptr;
+    return 0;
+}
+
 extern "C" {
 
 const char* wx_last_error(void) { return g_err.c_str(); }
@@ -285,6 +303,7 @@ int wx_create(const wx_config* cfg, wx_engine** out) {
     if (r == hipSuccess) r = hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming);
     if (r == hipSuccess) r = hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming);
     if (r != hipSuccess) { delete e; return fail(WX_ERR_HIP, hipGetErrorString(r)); }
+    if (int rs = resolve_static_scratch(e)) { wx_destroy(e); return rs; }     // once per engine, with its device current
     *out = e;
     return WX_OK;
 }
@@ -558,6 +577,29 @@ int wx_mel_stage2(wx_engine* e, float* d_logmel, int64_t ld, int64_t n_frames, c
     DeviceScope dev_scope(e);
     if (!d_logmel || !d_max || n_frames < 0 || ld < n_frames) return fail(WX_ERR_INVALID, "bad mel arguments");
     WX_TRY(launch_mel_stage2(d_logmel, ld, e->cfg.n_mels, n_frames, d_max, (hipStream_t)stream));
+    return WX_OK;
+}
+
+int wx_log_mel_static(wx_engine* e, const float* d_pcm, int64_t n_samples, int64_t padding, float* d_logmel, int64_t ld, void* stream) {
+    if (!e || !e->finalized) return fail(WX_ERR_STATE, "engine not finalized");
+    DeviceScope dev_scope(e);
+    if (!d_pcm || !d_logmel || n_samples <= 0 || padding < 0) return fail(WX_ERR_INVALID, "bad mel arguments");
+    const int64_t n_total = n_samples + padding, n_frames = n_total / HOP;
+    if (n_total < N_FFT) return fail(WX_ERR_INVALID, "audio shorter than one STFT window");
+    if (ld < n_frames) return fail(WX_ERR_INVALID, "bad mel arguments (ld < frame count)");
+    const int64_t max_frames = (int64_t)(WX_STATIC_FLOATS - WX_STATIC_HEAD) * 8;      // 8 frames per stage-1 workgroup
+    if (n_frames > max_frames)
+        return fail(WX_ERR_INVALID, "wx_log_mel_static: " + std::to_string(n_frames) + " frames exceed the static scratch (" +
+                                    std::to_string(max_frames) + " frames = 87 min of audio including padding); use wx_mel_stage1/2");
+    float* ptr = e->static_scratch;                      // this device's copy of `scratch`
+    if (!ptr) return fail(WX_ERR_STATE, "static scratch address was not resolved");
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = mel_stage1_blocks(n_frames);
+    if (blocks > WX_STATIC_FLOATS - WX_STATIC_HEAD) return fail(WX_ERR_INVALID, "wx_log_mel_static: grid exceeds the static scratch");
+    // nothing has to start at zero: the launch below overwrites slots [HEAD, HEAD + blocks), the fold reads exactly those
+    WX_TRY(launch_mel_stage1(e->mel, d_pcm, 0, n_samples, n_samples, n_total, 0, n_frames, d_logmel, ld, ptr, st, ptr + WX_STATIC_HEAD));
+    WX_TRY(launch_mel_fold_block_max(ptr + WX_STATIC_HEAD, blocks, ptr, st));
+    WX_TRY(launch_mel_stage2(d_logmel, ld, e->cfg.n_mels, n_frames, ptr, st));
     return WX_OK;
 }
 

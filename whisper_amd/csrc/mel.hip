@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256, 4) void mel_stage1_kernel(
     const float* __restrict__ window, const float* __restrict__ cs_tab, const float* __restrict__ filters, int n_pack,
     const int32_t* __restrict__ frange, int n_mels, const float* __restrict__ pcm, int64_t pcm_offset,
     int64_t n_valid, int64_t n_file, int64_t n_total, int64_t frame0, int64_t n_frames, float* __restrict__ out,
-    int64_t ld, float* d_max) {
+    int64_t ld, float* d_max, float* block_max) {
     __shared__ __attribute__((aligned(16))) float s_cs[N_FFT * 2];          // cos, sin of 2*pi*i/400
     __shared__ __attribute__((aligned(16))) float s_a[LDS_Y];               // PCM span, then the Y_r[q] records
     __shared__ __attribute__((aligned(16))) float s_b[LDS_EO];              // folded inputs e | o, then power[k]
@@ -222,7 +222,25 @@ __global__ __launch_bounds__(256, 4) void mel_stage1_kernel(
     __syncthreads();
     if (tid == 0) {
         const float v = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-        if (v > -INFINITY) atomic_max_float(d_max, v);
+        // block_max (wx_log_mel_static): one plain store per workgroup into the caller's partial-maximum array, folded by
+        // mel_fold_block_max_kernel afterwards; otherwise one atomic into the running maximum
+        if (block_max) block_max[blockIdx.x] = v;
+        else if (v > -INFINITY) atomic_max_float(d_max, v);
+    }
+}
+
+// out[0] = max(part[0 .. n)): the per-workgroup maxima of one mel_stage1 launch (one workgroup; n <= a few 10^4)
+__global__ __launch_bounds__(1024) void mel_fold_block_max_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+    __shared__ float s_red[16];
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, part[i]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) m = fmaxf(m, s_red[w]);
+        out[0] = m;
     }
 }
 
@@ -326,16 +344,24 @@ __global__ void fill_f32_kernel(float* p, float v, int64_t n) {
 
 int launch_mel_stage1(const MelTables& t, const float* pcm, int64_t pcm_offset, int64_t n_valid, int64_t n_file,
                       int64_t n_total, int64_t frame0, int64_t n_frames, float* out, int64_t ld, float* d_max,
-                      hipStream_t st) {
+                      hipStream_t st, float* block_max) {
     if (n_frames <= 0) return 0;
     if (t.n_mels > 256 || ld < n_frames) return -1;
     const int64_t blocks = (n_frames + MEL_FT - 1) / MEL_FT;
     if (t.n_pack <= MEL_PACK_LDS)
         hipLaunchKernelGGL(mel_stage1_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, t.window, t.cs, t.filters, t.n_pack,
-                           t.frange, t.n_mels, pcm, pcm_offset, n_valid, n_file, n_total, frame0, n_frames, out, ld, d_max);
+                           t.frange, t.n_mels, pcm, pcm_offset, n_valid, n_file, n_total, frame0, n_frames, out, ld, d_max, block_max);
     else
         hipLaunchKernelGGL(mel_stage1_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, t.window, t.cs, t.filters, t.n_pack,
-                           t.frange, t.n_mels, pcm, pcm_offset, n_valid, n_file, n_total, frame0, n_frames, out, ld, d_max);
+                           t.frange, t.n_mels, pcm, pcm_offset, n_valid, n_file, n_total, frame0, n_frames, out, ld, d_max, block_max);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int mel_stage1_blocks(int64_t n_frames) { return (int)((n_frames + MEL_FT - 1) / MEL_FT); }
+
+int launch_mel_fold_block_max(const float* part, int n, float* out, hipStream_t st) {
+    if (n <= 0 || !part || !out) return -1;
+    hipLaunchKernelGGL(mel_fold_block_max_kernel, dim3(1), dim3(1024), 0, st, part, n, out);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -160,6 +160,13 @@ class WhisperEngine:
         self.mel_stage2(out, n_frames, gmax)
         return out
 
+    def log_mel_static(self, pcm: torch.Tensor, out: torch.Tensor, padding: int = N_SAMPLES) -> None:
+        """``log_mel`` through the allocation-free entry point (``wx_log_mel_static``): the caller provides the device input
+        and the ``[n_mels, >= (len + padding) // 160]`` output; nothing is allocated, no workspace is passed."""
+        assert pcm.dtype == torch.float32 and pcm.is_cuda and pcm.is_contiguous() and out.dtype == torch.float32 and out.is_cuda
+        _lib.check(self.lib.wx_log_mel_static(self.handle, _ptr(pcm), pcm.numel(), int(padding), _ptr(out), out.stride(0),
+                                              self._stream()), "wx_log_mel_static")
+
     def mel_stage2(self, mel: torch.Tensor, n_frames: int, gmax: torch.Tensor) -> None:
         _lib.check(self.lib.wx_mel_stage2(self.handle, _ptr(mel), mel.stride(0), n_frames, _ptr(gmax), self._stream()),
                    "wx_mel_stage2")
