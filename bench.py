@@ -49,46 +49,138 @@ def parse():
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real multi-GPU path) | gloo (rehearsal of the N>1 code path)")
     p.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
-    p.add_argument("--cpu-decode-steps", type=int, default=24)
+    p.add_argument("--cpu-decode-steps", type=int, default=0, help="0 = as many greedy steps as the GPU run took (no extrapolation)")
     p.add_argument("--no-profile-pass", action="store_true", help="skip the event-bracketed eager pass (PMC runs)")
+    p.add_argument("--dry-run", action="store_true", help="launcher rehearsal: every rank reports its rank environment and exits before touching the GPU")
     return p.parse_args()
 
 
+def host_cores():
+    """(threads to use, physical cores, how they were found).  Physical cores = distinct (physical id, core id) pairs of
+    /proc/cpuinfo; the threads actually used are bounded by this process's CPU share: its affinity mask and the harness's
+    OMP_NUM_THREADS (the GPU box shows the whole machine in nproc but grants a 16-CPU share per GPU)."""
+    phys, how = None, ""
+    try:
+        pairs, cur = set(), {}
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if ":" in line:
+                    k, v = [x.strip() for x in line.split(":", 1)]
+                    cur[k] = v
+                elif not line.strip():
+                    if "core id" in cur:
+                        pairs.add((cur.get("physical id", "0"), cur["core id"]))
+                    cur = {}
+        if "core id" in cur:
+            pairs.add((cur.get("physical id", "0"), cur["core id"]))
+        if pairs:
+            phys, how = len(pairs), "/proc/cpuinfo distinct (physical id, core id)"
+    except OSError:
+        pass
+    if not phys:
+        phys, how = os.cpu_count() or 1, "os.cpu_count() (no core ids in /proc/cpuinfo)"
+    limit = [phys]
+    try:
+        limit.append(len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    if os.environ.get("OMP_NUM_THREADS", "").isdigit():
+        limit.append(int(os.environ["OMP_NUM_THREADS"]))
+    return max(1, min(limit)), phys, how + f"; threads = min(physical, affinity, OMP_NUM_THREADS) = {max(1, min(limit))}"
+
+
 def cpu_baseline(dims, sd, tok, suppress_ids, gpu_steps_per_window: int, decode_steps: int):
-    """Oracle (kind 'port') on the host cores: one window of the same workload; decode timed over `decode_steps`
-    steps and extrapolated linearly to the GPU run's step count (decode cost per step is constant up to the small
-    self-attention term)."""
+    """Oracle (kind 'port') on the host cores.  (1) one window of the SAME workload as the GPU line: mel, encoder and the
+    full greedy decode (as many steps as the GPU run took per window: nothing is extrapolated unless --cpu-decode-steps
+    shortens it).  (2) BASELINE.json configs[0] exactly: Whisper tiny fp32 greedy on one 30 s synthetic clip (seed 0),
+    sample_len steps -- the reference's own CPU-runnable case."""
     from oracle import whisper_oracle as wo
-    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    cores, phys, how = host_cores()
     torch.set_num_threads(cores)
-    om = wo.OracleWhisper(dims, sd)
     audio = synthetic_audio(0)
-    init = wo.initial_tokens(tok, 0)
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        mel = wo.log_mel_spectrogram(audio, dims.n_mels, padding=wo.N_SAMPLES)[:, :wo.N_FRAMES]
-        t1 = time.perf_counter()
-        xa = om.encode(mel[None])
-        t2 = time.perf_counter()
-        r = wo.greedy_decode(om, xa, init, tok, suppress_ids, max_new_tokens=decode_steps)
-        t3 = time.perf_counter()
-    per_step = (t3 - t2) / max(1, r["steps"])
-    total = (t1 - t0) + (t2 - t1) + per_step * gpu_steps_per_window
-    return {
-        "value": 30.0 / total, "unit": "audio-sec/sec", "cores": cores, "kind": "port",
-        "sample": (f"oracle/whisper_oracle.py (PyTorch fp32) on 1 window of the same workload: mel {t1 - t0:.2f}s, encoder "
-                   f"{t2 - t1:.2f}s, {r['steps']} greedy steps {t3 - t2:.2f}s, decode extrapolated linearly to "
-                   f"{gpu_steps_per_window} steps; weight load excluded"),
+
+    def run(dims_, sd_, sup_, n_steps, warm):
+        om = wo.OracleWhisper(dims_, sd_)
+        tok_ = ck.special_tokens_for(dims_.n_vocab)
+        init = wo.initial_tokens(tok_, 0)
+        with torch.no_grad():
+            if warm:        # one untimed pass (thread pool, allocator); skipped for the large model, where it would double the run
+                xw = om.encode(wo.log_mel_spectrogram(audio, dims_.n_mels, padding=wo.N_SAMPLES)[None, :, :wo.N_FRAMES])
+                wo.greedy_decode(om, xw, init, tok_, sup_, max_new_tokens=4)
+            t0 = time.perf_counter()
+            mel = wo.log_mel_spectrogram(audio, dims_.n_mels, padding=wo.N_SAMPLES)[:, :wo.N_FRAMES]
+            t1 = time.perf_counter()
+            xa = om.encode(mel[None])
+            t2 = time.perf_counter()
+            r = wo.greedy_decode(om, xa, init, tok_, sup_, max_new_tokens=n_steps)
+            t3 = time.perf_counter()
+        return t1 - t0, t2 - t1, t3 - t2, int(r["steps"])
+
+    n = decode_steps if decode_steps > 0 else gpu_steps_per_window
+    t_mel, t_enc, t_dec, steps = run(dims, sd, suppress_ids, n, warm=dims.n_audio_state <= 768)
+    per_step = t_dec / max(1, steps)
+    total = t_mel + t_enc + per_step * gpu_steps_per_window
+    extrap = "" if steps == gpu_steps_per_window else f", decode extrapolated linearly from {steps} to {gpu_steps_per_window} steps"
+    out = {
+        "value": 30.0 / total, "unit": "audio-sec/sec", "cores": cores, "physical_cores": phys, "cores_source": how, "kind": "port",
+        "sample": (f"oracle/whisper_oracle.py (PyTorch fp32) on 1 window of the same workload: mel {t_mel:.2f}s, encoder "
+                   f"{t_enc:.2f}s, {steps} greedy steps {t_dec:.2f}s{extrap}; weight load excluded"),
     }
+    d0 = ck.dims_for("tiny")
+    sd0 = ck.synthetic_state_dict(d0, seed=0)
+    from whisper_amd.engine import default_suppress_ids
+    tok0 = ck.special_tokens_for(d0.n_vocab)
+    m0, e0, c0, s0 = run(d0, sd0, default_suppress_ids(tok0, d0.n_vocab), d0.n_text_ctx // 2, warm=True)
+    out["config0"] = {
+        "workload": "BASELINE.json configs[0]: Whisper tiny fp32 greedy, one 30 s synthetic clip (seed 0), CPU oracle, full decode",
+        "value": 30.0 / (m0 + e0 + c0), "unit": "audio-sec/sec", "seconds": m0 + e0 + c0, "mel_s": m0, "encoder_s": e0,
+        "decode_s": c0, "decode_steps": s0, "cores": cores,
+    }
+    return out
+
+
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` with no launcher around it: start N fresh rank processes of this script (one per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1), relay rank 0's JSON line, and fail if any rank
+    fails.  This parent never touches the GPU (no process that has initialised HIP is ever replaced or forked)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"bench.py: ranks failed: {bad}", file=sys.stderr)
+        return 1
+    return 0
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run:
+        if os.environ.get("BENCH_DRY_RUN_FAIL_RANK") == str(rank):
+            raise SystemExit(3)
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "rank": rank, "local_rank": local_rank, "master_addr": os.environ.get("MASTER_ADDR"),
+                              "master_port": os.environ.get("MASTER_PORT"), "dry_run": True}), flush=True)
+        return
     if args.one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -192,14 +284,19 @@ def main():
         bytes_per_launch = B * dims.n_text_head * 2 * dims.n_audio_ctx * 64 * es      # K and V of every (b, h), read once
         avg_ms = prof_ms / max(1, prof_n)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if prof_n else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_cross_attn_pmc.json")
-        # the committed PMC pass is of the default workload's launch; other shapes report no traffic figure
-        if os.path.exists(pmc) and (args.model, B, args.precision) == ("large-v3", 64, "bf16"):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        # traffic: HBM bytes per launch from a rocprofv3 --pmc pass of THIS command (TCC FETCH_SIZE with the guide's gfx950
+        # corrections), committed under profiles/ -- a replayed constant, not something this run measured; other shapes
+        # than the default workload's report none
+        traffic, traffic_source = None, None
+        for name in ("r02_cross_attn_pmc.json", "r01_cross_attn_pmc.json"):
+            pmc = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(pmc) and (args.model, B, args.precision) == ("large-v3", 64, "bf16"):
+                try:
+                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                    traffic_source = f"profiles/{name} (separate rocprofv3 --pmc pass of this command; not measured in this run)"
+                    break
+                except Exception:
+                    traffic = None
         out = {
             "metric": "audio-sec/sec (RTFx) whole node, large-v3 greedy, 1/2/4/8 MI355X",
             "value": value, "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -216,7 +313,7 @@ def main():
             "roofline": {
                 "kernel": "attn_decode_kernel<bf16,1> (decoder cross-attention)" if es == 2 else "attn_decode_kernel<float>",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms, "launches_timed": prof_n,
             },
         }

@@ -39,6 +39,12 @@ class OracleEngine:
     def mel_stage2(self, mel, n_frames, gmax):
         mel[:, :n_frames] = (torch.maximum(mel[:, :n_frames], gmax - 8.0) + 4.0) / 4.0
 
+    def detect_language(self, mel, n_content):
+        seg = wo.pad_or_trim_frames(mel[:, :min(N_FRAMES, max(n_content, 0))])
+        with torch.no_grad():
+            lg = self.om.logits(torch.tensor([[self.tok.sot]]), self.om.encode(seg[None]))[0, 0]
+        return int(lg[self.tok.sot + 1: self.tok.sot + 1 + self.tok.n_langs].argmax())
+
     def transcribe_mel(self, mel, n_content, w_lo, w_hi, prompt, **kw):
         segs = []
         for w in range(w_lo, w_hi):
@@ -59,9 +65,10 @@ def _worker(rank, world, port, n_samples, q):
     eng = OracleEngine(dims, sd, max_new=12)
     audio = wo.varied_audio(21, n_samples)
     audio[: n_samples // 3] *= 0.02          # the global mel maximum lives in rank 1's share
-    init = wo.initial_tokens(eng.tok, 0)
-    out = wdist.transcribe_sharded(eng, audio, init)
-    q.put((rank, out["tokens"], out["sum_logprobs"], out["n_windows"], out["local_windows"]))
+    # a callable prompt: the language is detected on rank 0's window 0 (whole-file clamp, known after the MAX all-reduce)
+    # and broadcast, then every rank builds the same prompt
+    out = wdist.transcribe_sharded(eng, audio, lambda li: wo.initial_tokens(eng.tok, li))
+    q.put((rank, out["tokens"], out["sum_logprobs"], out["n_windows"], out["local_windows"], out["language_index"]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -84,11 +91,16 @@ def test_two_rank_sharding_matches_single_process():
     tok = ck.special_tokens_for(dims.n_vocab)
     audio = wo.varied_audio(21, n_samples)
     audio[: n_samples // 3] *= 0.02
+    om = wo.OracleWhisper(dims, sd)
     with torch.no_grad():
-        ref = wo.transcribe_windows(wo.OracleWhisper(dims, sd), audio, wo.initial_tokens(tok, 0), tok,
+        mel = wo.log_mel_spectrogram(audio, dims.n_mels, padding=wo.N_SAMPLES)          # whole file, whole-file clamp
+        lg = om.logits(torch.tensor([[tok.sot]]), om.encode(mel[None, :, :N_FRAMES]))[0, 0]
+        lang = int(lg[tok.sot + 1: tok.sot + 1 + tok.n_langs].argmax())
+        ref = wo.transcribe_windows(om, audio, wo.initial_tokens(tok, lang), tok,
                                     wo.suppress_token_ids(tok, ck.non_speech_suppress_ids()), max_new_tokens=12)
     assert ref["n_windows"] == 4
-    for rank, toks, sums, nw, local in sorted(got):
+    for rank, toks, sums, nw, local, li in sorted(got):
+        assert li == lang
         assert nw == 4 and local == ((0, 2) if rank == 0 else (2, 4))
         assert toks == ref["tokens"]                      # every rank holds the full, window-ordered result
         np.testing.assert_allclose(sums, ref["sum_logprobs"], rtol=1e-4, atol=1e-3)
@@ -103,3 +115,29 @@ def test_single_process_path_needs_no_process_group():
     assert out["n_windows"] == 2 and len(out["tokens"]) == 2 and out["local_windows"] == (0, 2)
     assert wdist.local_sample_range(10_000_000, 2, 4) == (2 * 480000 - 200, 4 * 480000 + 200)
     assert wdist.local_sample_range(500_000, 0, 2) == (0, 500_000)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` with no launcher and no rank environment starts N rank processes itself (rendezvous on
+    127.0.0.1), relays rank 0's line and fails when any rank fails; under a launcher (WORLD_SIZE set) it does not re-launch
+    and refuses a --gpus that disagrees with the world size.  --dry-run: the ranks stop before touching the GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["rank"] == 0 and line["master_addr"] == "127.0.0.1" and int(line["master_port"]) > 0
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=dict(env, BENCH_DRY_RUN_FAIL_RANK="1"),
+                         capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "ranks failed" in bad.stderr
+    under = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"],
+                           env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert under.returncode == 0 and json.loads(under.stdout.strip().splitlines()[-1])["n_gpus"] == 2
+    wrong = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"],
+                           env=dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert wrong.returncode != 0
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run"], env=env, capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0 and json.loads(one.stdout.strip().splitlines()[-1])["n_gpus"] == 1
