@@ -121,13 +121,14 @@ def test_transcribe_contract_and_dropin(tmp_path, monkeypatch):
         tx.close()
 
 
-def test_properties_at_scale_bf16():
-    """Size-independent properties on a base-size model at batch 16 (BASELINE configs[1] shape): window results do not
+@pytest.mark.parametrize("model", ["base", "small"])
+def test_properties_at_scale_bf16(model):
+    """Size-independent properties on base- and small-size models at batch 16 (BASELINE configs[1]): window results do not
     depend on the batch they were decoded in, nor on graph vs eager launches; rows are EOT padded; mel is window-local
     away from the clamp."""
     from whisper_amd.audio import synthetic_audio
     from whisper_amd.engine import WhisperEngine
-    dims = ck.dims_for("base")
+    dims = ck.dims_for(model)
     eng = WhisperEngine(dims, ck.synthetic_state_dict(dims, 0, eot_boost=3.0), precision="bf16", max_batch=16)
     try:
         pcm = torch.from_numpy(np.concatenate([synthetic_audio(s) for s in range(16)])).cuda()
@@ -285,3 +286,168 @@ def test_transcribe_modes_beam_and_sequential(tmp_path):
             tx.transcribe(audio, language="en", mode="nope")
     finally:
         tx.close()
+
+
+def _toy_vocab(path, n_ids=50257):
+    """A tiktoken-format vocabulary for tests: the 256 byte tokens, then one word " w<i>" per id -- every id the synthetic
+    model can emit decodes to real text (so "the last 20 words" exist), and text prompts encode to byte tokens."""
+    import base64
+    lines = [base64.b64encode(bytes([i])) + b" " + str(i).encode() for i in range(256)]
+    lines += [base64.b64encode(f" w{i}".encode()) + b" " + str(i).encode() for i in range(256, n_ids)]
+    with open(path, "wb") as f:
+        f.write(b"\n".join(lines) + b"\n")
+
+
+def test_large_file_path_end_to_end(tmp_path):
+    """The reference's large-file path (ref:app/transcription/openai_whisper.py:268-337) against a LIVE engine: a 14-minute
+    16 kHz PCM16 WAV (26.9 MB > the 25 MB limit) is cut into 20 MB pieces by duration, the pieces are transcribed in order
+    with the last 20 words of the previous piece carried in the prompt, texts are joined with spaces, the piece files are
+    removed; the result equals per-piece transcribe() calls made by hand with the same prompts."""
+    import wave
+    from oracle import whisper_oracle as wo
+    from whisper_amd import large_audio as la
+    from whisper_amd import transcribe as tx
+    vocab = str(tmp_path / "toy.tiktoken")
+    _toy_vocab(vocab)
+    tx.configure(model="micro", precision="fp32", max_batch=8, allow_synthetic_weights=True, vocab=vocab)
+    try:
+        seconds = 14 * 60
+        audio = np.concatenate([wo.varied_audio(200 + i, 16000 * 60) for i in range(seconds // 60)])
+        pcm = np.clip(np.rint(audio * 32767.0), -32768, 32767).astype(np.int16)
+        p = tmp_path / "long.wav"
+        with wave.open(str(p), "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(pcm.tobytes())
+        assert p.stat().st_size / (1024 * 1024) > la.MAX_SINGLE_CALL_MB
+        kw = dict(mode="windows", max_new_tokens=24)
+        pieces = asyncio.run(la.chunk_large_audio(p))
+        assert len(pieces) == 2 and pieces[0].parent == tmp_path / "long_chunks"
+        r1 = tx.transcribe(str(pieces[0]), language="en", prompt="hello", **kw)
+        assert len(r1["text"].split()) >= 20
+        carried = "hello Previous context: " + " ".join(r1["text"].strip().split()[-20:])
+        r2 = tx.transcribe(str(pieces[1]), language="en", prompt=carried, **kw)
+        assert r2["tokens"] != tx.transcribe(str(pieces[1]), language="en", prompt="hello", **kw)["tokens"]   # the carry-over matters
+        text, conf, lang, source = asyncio.run(la.transcribe_large_audio(p, True, "en", "hello", **kw))
+        assert source == "chunked" and lang == "en" and conf == 0.0
+        assert text == r1["text"].strip() + " " + r2["text"].strip()
+        assert not (tmp_path / "long_chunks").exists() and p.exists()
+        assert r1["chunks_processed"] + r2["chunks_processed"] == 21 + 8        # 624.3 s and 215.7 s pieces
+        # under the limit: one local call, source "local"
+        small = tmp_path / "small.wav"
+        with wave.open(str(small), "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(pcm[: 16000 * 40].tobytes())
+        out = asyncio.run(la.transcribe_large_audio(small, True, "en", None, **kw))
+        assert out[3] == "local" and out[0] == tx.transcribe(str(small), language="en", **kw)["text"].strip()
+        # the default piece mode is upstream's sequential loop
+        seq = asyncio.run(la.transcribe_large_audio(small, True, "en", None, max_new_tokens=8, temperatures=(0.0,)))
+        assert seq[3] == "local" and seq[0] == tx.transcribe(str(small), language="en", mode="sequential", max_new_tokens=8,
+                                                             temperatures=(0.0,))["text"].strip()
+    finally:
+        tx.close()
+
+
+@pytest.mark.parametrize("fmt", ["pt", "safetensors"])
+def test_engine_from_a_checkpoint_file(tmp_path, fmt):
+    """ref:app/transcription/speech_recognition.py:22 (whisper.load_model) -> configure(checkpoint=...): an engine built from
+    a LOCAL openai-layout .pt / HF-layout .safetensors file decodes the ids of the engine built from the in-memory state
+    dict, and the dimensions come from the file, not from the model name."""
+    from oracle import whisper_oracle as wo
+    from whisper_amd import transcribe as tx
+    from whisper_amd.engine import WhisperEngine
+    dims = ck.dims_for("micro")
+    sd = ck.synthetic_state_dict(dims, seed=5, eot_boost=3.0)
+    path = str(tmp_path / f"model.{fmt}")
+    if fmt == "pt":
+        ck.save_checkpoint(path, dims, sd)
+    else:
+        from safetensors.torch import save_file
+        hf = {ck.canonical_to_hf_name(k): v.contiguous() for k, v in sd.items()}
+        hf["proj_out.weight"] = sd["decoder.token_embedding.weight"].clone()       # HF files carry the tied head too
+        save_file(hf, path)
+    audio = wo.varied_audio(12, 16000 * 50)
+    ref_eng = WhisperEngine(dims, sd, precision="fp32", max_batch=2)
+    try:
+        want = ref_eng.transcribe_pcm(audio, ref_eng.initial_tokens(0), max_new_tokens=16)["tokens"]
+    finally:
+        ref_eng.close()
+    eng = tx.configure(model="large-v3", checkpoint=path, precision="fp32", max_batch=2)     # the name is NOT what sizes the engine
+    try:
+        assert eng.dims == dims
+        got = tx.transcribe(audio, language="en", max_new_tokens=16)
+        assert got["tokens"] == want and got["chunks_processed"] == 2
+        om = wo.OracleWhisper(dims, sd)
+        with torch.no_grad():
+            ref = wo.transcribe_windows(om, audio, eng.initial_tokens(0), eng.tok, eng.suppress_ids, max_new_tokens=16)
+        assert got["tokens"] == ref["tokens"]
+    finally:
+        tx.close()
+    with pytest.raises(FileNotFoundError):
+        tx.configure(model="micro", checkpoint=str(tmp_path / "missing.pt"))
+
+
+def test_confidence_mode_avg_logprob(tmp_path, monkeypatch):
+    """confidence_mode="avg_logprob" returns exp(mean over windows of sum_logprob / (n_tokens + 1)) -- the
+    oracle's number -- through transcribe() and through the drop-in (capped at 0.5 on the privacy branch); the default
+    "reference" mode returns the reference's 0.0 (it reads a segment key upstream does not set, ref:speech_recognition.py:62-66)."""
+    import math
+    from oracle import whisper_oracle as wo
+    from whisper_amd import audio as wa
+    from whisper_amd import transcribe as tx
+    eng = tx.configure(model="micro", precision="fp32", max_batch=4, allow_synthetic_weights=True, confidence_mode="avg_logprob", seed=0)
+    try:
+        p = str(tmp_path / "c.wav")
+        wa.save_wav_pcm16(p, wo.varied_audio(15, 16000 * 70))
+        audio = wa.load_wav_pcm16(p)                                  # the PCM16-quantised samples, as float32
+        om = wo.OracleWhisper(eng.dims, ck.synthetic_state_dict(eng.dims, seed=0))
+        with torch.no_grad():
+            ref = wo.transcribe_windows(om, audio, eng.initial_tokens(0), eng.tok, eng.suppress_ids, max_new_tokens=20)
+        avg = [float(s) / (len(t) + 1) for s, t in zip(ref["sum_logprobs"], ref["tokens"])]
+        want = math.exp(sum(avg) / len(avg))
+        got = tx.transcribe(p, language="en", max_new_tokens=20)
+        assert got["tokens"] == ref["tokens"]
+        assert 0.0 < got["confidence"] < 1.0 and abs(got["confidence"] - want) < 1e-3 * want
+        # sequential mode: exp(mean of the segments' avg_logprob)
+        s = tx.transcribe(p, language="en", mode="sequential", max_new_tokens=20, temperatures=(0.0,))
+        from whisper_amd.tokenizer import Tokenizer
+        with torch.no_grad():
+            rs = wo.transcribe_sequential(om, audio, eng.tok, eng.suppress_ids, Tokenizer(eng.dims.n_vocab).decode, max_new_tokens=20)
+        lps = [sg["avg_logprob"] for sg in rs["segments"]]
+        assert lps and abs(s["confidence"] - math.exp(sum(lps) / len(lps))) < 1e-3 * s["confidence"]
+        import whisper_amd.speech_recognition as sr
+        monkeypatch.setattr(sr, "whisper_model", eng)
+        monkeypatch.setattr(sr, "LANGUAGE", "en")
+        monkeypatch.setattr(sr, "_AMD", {"decode_mode": "windows"})
+        full = tx.transcribe(p, language="en")["confidence"]
+        text, conf, lang = asyncio.run(sr.transcribe_audio(p, detailed=True))
+        assert abs(conf - full) < 1e-12 and lang == "en"
+        assert asyncio.run(sr.transcribe_audio(p, detailed=False))[1] == min(full, 0.5)
+    finally:
+        tx.close()
+    tx.configure(model="micro", precision="fp32", max_batch=4, allow_synthetic_weights=True)
+    try:
+        assert tx.transcribe(p, language="en", max_new_tokens=4)["confidence"] == 0.0
+    finally:
+        tx.close()
+
+
+def test_timing_harness_prints_the_reference_lines(tmp_path, capsys, monkeypatch):
+    """ref:test_whisper.py:13-54: `python -m whisper_amd.harness clip.wav --model tiny` loads the model by name inside the
+    timed region and prints the reference's summary block, in its order and format."""
+    import re
+    import sys
+    from oracle import whisper_oracle as wo
+    from whisper_amd import audio as wa
+    from whisper_amd import harness
+    p = str(tmp_path / "clip.wav")
+    wa.save_wav_pcm16(p, wo.varied_audio(3, 16000 * 12))
+    monkeypatch.setattr(sys, "argv", ["harness", p, "--model", "tiny", "--language", "en"])
+    harness.main()
+    out = capsys.readouterr().out.splitlines()
+    assert out[0] == "Loading Whisper model 'tiny'..." and out[1] == f"Transcribing {p} on cuda..."
+    i = out.index("Transcription Results:")
+    assert out[i - 1] == "" and out[i + 1] == "=" * 50
+    assert out[i + 2].startswith("Text: ") and out[i + 3] == "Language: en"
+    assert re.fullmatch(r"Confidence: \d+\.\d{4}", out[i + 4]) and re.fullmatch(r"Time taken: \d+\.\d{2} seconds", out[i + 5])
+    assert out[i + 6] == "=" * 50
+    monkeypatch.setattr(sys, "argv", ["harness", str(tmp_path / "nope.wav")])
+    harness.main()
+    assert capsys.readouterr().out.strip() == f"Error: Audio file '{tmp_path / 'nope.wav'}' not found"

@@ -12,10 +12,18 @@ from whisper_amd import checkpoint as ck
 pytestmark = pytest.mark.gpu
 
 FP32_TOL = 2e-4     # max |hip - oracle| / max |oracle|, fp32 mode (different summation order only)
-# bf16 mode (bf16 weights/activations, fp32 accumulate, fp32 residual), metric ||hip - oracle|| / ||oracle||:
-BF16_RMS_TOL = 1.5e-2        # on smooth-attention weights (attn_gain 1): pure rounding noise of the bf16 pipeline
-BF16_RMS_TOL_SHARP = 2.5e-1  # on the default sharp-attention weights (attn_gain 3): a bf16-rounded q.k score (|s| up to
-                             # ~40, ulp 2^-8 relative) re-weights the softmax, so outputs move by several percent
+# bf16 mode (bf16 weights/activations, fp32 accumulate, fp32 residual), metric ||hip - ref|| / ||ref||:
+BF16_RMS_TOL = 1.5e-2        # against the fp32 oracle on smooth-attention weights (attn_gain 1): the rounding noise of the bf16 pipeline
+# Against the oracle's bf16-EMULATING mode (same rounding points as the engine), on any weights, the sharp default ones
+# (attn_gain 3) included: bf16 rounding amplifies a summation-order difference of 1e-6 to a whole ulp wherever a rounding
+# flips, so two correct evaluations of the same rounded model sit one NOISE FLOOR apart -- measured here as the distance
+# between the emulation with fp32 and with fp64 accumulation.  The device must be within BF16_NOISE_FACTOR noise floors of
+# the emulation (measured: 1.0-1.2 once the stack is deep enough for the noise to saturate, 1.7 on the 2-layer micro model,
+# where the flash kernel's running-maximum rounding of P -- the emulation rounds against the final maximum -- still shows;
+# a broken kernel is tens of floors away).  A flat 2e-2 holds on smooth
+# weights and for tiny's encoder, but not for sharp 32-layer stacks whose own noise floor is 5-8e-2 -- and the old flat
+# 2.5e-1 against the fp32 oracle would have passed a broken kernel.
+BF16_NOISE_FACTOR = 2.0
 
 
 def rel_err(a, b):
@@ -28,11 +36,19 @@ def rms_err(a, b):
     return float(np.sqrt(((a - b) ** 2).sum() / max((b ** 2).sum(), 1e-30)))
 
 
-def check_close(got, ref, precision, sharp=True):
+def check_close(got, ref, precision, sharp=True, emu=None, emu64=None):
+    """fp32: against the fp32 oracle.  bf16: within BF16_NOISE_FACTOR noise floors (|emu64 - emu|) of the bf16-emulating
+    oracle, and on smooth weights also against the fp32 oracle at BF16_RMS_TOL."""
     if precision == "fp32":
         assert rel_err(got, ref) < FP32_TOL
-    else:
-        assert rms_err(got, ref) < (BF16_RMS_TOL_SHARP if sharp else BF16_RMS_TOL)
+        return
+    if emu is not None:
+        e, floor = rms_err(got, emu), rms_err(emu64, emu)
+        print(f"\nbf16 vs emulation {e:.3e} = {e / floor:.2f} noise floors ({floor:.3e}); vs fp32 oracle {rms_err(got, ref):.3e} "
+              f"({'sharp' if sharp else 'smooth'} weights)")
+        assert e < BF16_NOISE_FACTOR * floor
+    if not sharp or emu is None:
+        assert rms_err(got, ref) < BF16_RMS_TOL
 
 
 @pytest.fixture(scope="module")
@@ -107,24 +123,30 @@ def test_mel_two_stage_matches_sharded_max(models):
 
 
 @pytest.mark.parametrize("name,precision,gain", [("micro", "fp32", 3.0), ("tiny", "fp32", 3.0), ("micro", "bf16", 1.0),
-                                                 ("tiny", "bf16", 1.0), ("tiny", "bf16", 3.0)])
+                                                 ("tiny", "bf16", 1.0), ("tiny", "bf16", 3.0), ("micro", "bf16", 3.0)])
 def test_encoder_and_logits_parity(models, name, precision, gain):
     dims, sd, eng = models(name, precision, attn_gain=gain)
     om = wo.OracleWhisper(dims, sd)
+    oe = wo.OracleWhisper(dims, sd, emulate_bf16=True) if precision == "bf16" else None
+    o64 = wo.OracleWhisper(dims, sd, emulate_bf16=True, acc_dtype=torch.float64) if precision == "bf16" else None
     mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(s), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000] for s in (0, 1)])
     with torch.no_grad():
         xa = om.encode(mels)
+        xe = oe.encode(mels) if oe else None
+        x64 = o64.encode(mels) if o64 else None
     eng.encode_windows(mels)
     got = eng.encoder_output(2).cpu()
-    check_close(got, xa, precision, sharp=gain > 1.0)
+    check_close(got, xa, precision, sharp=gain > 1.0, emu=xe, emu64=x64)
     tok = eng.tok
     toks = torch.tensor([[tok.sot, tok.lang(0), tok.transcribe, tok.no_timestamps, 100, 2000, 31337],
                          [tok.sot, tok.lang(3), tok.transcribe, tok.no_timestamps, 7, 50000, 421]])
     with torch.no_grad():
         ref = om.logits(toks, xa)
+        ref_e = oe.logits(toks, xe) if oe else None
+        ref_64 = o64.logits(toks, x64) if o64 else None
     lg = eng.decoder_logits(toks).cpu()
     assert lg.shape == ref.shape
-    check_close(lg, ref, precision, sharp=gain > 1.0)
+    check_close(lg, ref, precision, sharp=gain > 1.0, emu=ref_e, emu64=ref_64)
 
 
 def test_encoder_parity_256_tiles_bf16(models):

@@ -14,7 +14,8 @@ import os
 import time
 
 
-def transcribe_audio(audio_file, model_name="base", language=None, checkpoint=None, vocab=None, precision="bf16", repeat=0):
+def transcribe_audio(audio_file, model_name="base", language=None, checkpoint=None, vocab=None, precision="bf16", repeat=0,
+                     mode="sequential"):
     start_time = time.time()
     print(f"Loading Whisper model '{model_name}'...")
     import torch
@@ -23,7 +24,9 @@ def transcribe_audio(audio_file, model_name="base", language=None, checkpoint=No
     tx.configure(model=model_name, checkpoint=checkpoint, vocab=vocab, precision=precision, max_batch=16,
                  allow_synthetic_weights=checkpoint is None)
     print(f"Transcribing {audio_file} on {device}...")
-    result = tx.transcribe(audio_file, language=language)          # language None = auto-detection
+    # mode "sequential" = upstream's own long-form loop, what the reference's model.transcribe(audio_file, **options) runs
+    # (ref:test_whisper.py:31); "windows" = the batched independent-window mode
+    result = tx.transcribe(audio_file, language=language, mode=mode)          # language None = auto-detection
     torch.cuda.synchronize()
     text = result["text"].strip()
     language = result.get("language", "unknown")
@@ -38,7 +41,7 @@ def transcribe_audio(audio_file, model_name="base", language=None, checkpoint=No
     if repeat > 0:
         t0 = time.time()
         for _ in range(repeat):
-            tx.transcribe(audio_file, language=language)
+            tx.transcribe(audio_file, language=language, mode=mode)
         torch.cuda.synchronize()
         print(f"Steady state: {(time.time() - t0) / repeat:.3f} seconds per call ({result['chunks_processed']} x 30 s windows)")
     print("=" * 50)
@@ -56,11 +59,12 @@ def main():
     parser.add_argument("--vocab", help="local tiktoken vocabulary file")
     parser.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     parser.add_argument("--repeat", type=int, default=0)
+    parser.add_argument("--mode", default="sequential", choices=["sequential", "windows"])
     args = parser.parse_args()
     if not os.path.exists(args.audio_file):
         print(f"Error: Audio file '{args.audio_file}' not found")
         return
-    transcribe_audio(args.audio_file, args.model, args.language, args.checkpoint, args.vocab, args.precision, args.repeat)
+    transcribe_audio(args.audio_file, args.model, args.language, args.checkpoint, args.vocab, args.precision, args.repeat, args.mode)
 
 
 if __name__ == "__main__":

@@ -24,6 +24,9 @@ from typing import List, Optional, Tuple
 logger = logging.getLogger(__name__)
 
 MAX_SINGLE_CALL_MB = 25          # ref:openai_whisper.py:288
+# how a piece is decoded: "sequential" = upstream's own long-form loop (what the reference's local call runs), "windows" =
+# independent 30 s windows, batched and sharded (whisper_amd.transcribe)
+DECODE_MODE = "sequential"
 
 
 async def chunk_large_audio(audio_path: Path, chunk_size_mb: float = 20.0) -> List[Path]:
@@ -60,13 +63,14 @@ async def chunk_large_audio(audio_path: Path, chunk_size_mb: float = 20.0) -> Li
 
 
 async def transcribe_audio_local(audio_path: Path, detailed: bool = True, language: Optional[str] = None,
-                                 prompt: Optional[str] = None) -> Tuple[str, float, str, str]:
+                                 prompt: Optional[str] = None, **decode_kw) -> Tuple[str, float, str, str]:
     """The local branch of the reference's ``transcribe_audio_hybrid`` (ref:openai_whisper.py:138-153): source ``"local"`` on
     success, ``("", 0.0, "unknown", "failed")`` if the local call raises.  Unlike the reference, which drops ``language`` and
     ``prompt`` before the local call (:142), both reach the engine here."""
     from . import transcribe as tx
     try:
-        r = tx.transcribe(str(audio_path), language=language, prompt=prompt)
+        decode_kw.setdefault("mode", DECODE_MODE)
+        r = tx.transcribe(str(audio_path), language=language, prompt=prompt, **decode_kw)
         text, conf = r["text"].strip(), float(r["confidence"])
         if not detailed:                                          # ref:speech_recognition.py:69-72
             text, conf = "Voice authentication required for full transcription", min(conf, 0.5)
@@ -100,16 +104,18 @@ def _remove_pieces(pieces: List[Path], original: Path) -> None:
 
 
 async def transcribe_large_audio(audio_path: Path, detailed: bool = True, language: Optional[str] = None,
-                                 prompt: Optional[str] = None) -> Tuple[str, float, str, str]:
+                                 prompt: Optional[str] = None, **decode_kw) -> Tuple[str, float, str, str]:
+    """``decode_kw`` (not in the reference's signature): passed to ``whisper_amd.transcribe.transcribe`` for every piece
+    (``mode``, ``max_new_tokens``, ``temperatures`` ...)."""
     audio_path = Path(audio_path)
     if audio_path.stat().st_size / (1024 * 1024) <= MAX_SINGLE_CALL_MB:
-        return await transcribe_audio_local(audio_path, detailed, language, prompt)
+        return await transcribe_audio_local(audio_path, detailed, language, prompt, **decode_kw)
     pieces = await chunk_large_audio(audio_path)
     results: List[Tuple[str, float, str]] = []
     try:
         for piece in pieces:
             carried = _carry_prompt(prompt, results[-1][0] if results else None)
-            text, conf, lang, _ = await transcribe_audio_local(piece, detailed, language, carried)
+            text, conf, lang, _ = await transcribe_audio_local(piece, detailed, language, carried, **decode_kw)
             results.append((text, conf, lang))
     finally:
         _remove_pieces(pieces, audio_path)
