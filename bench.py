@@ -281,14 +281,17 @@ def main():
         es = 2 if args.precision == "bf16" else 4
         audio_sec = world * B * 30.0 * args.steps
         value = audio_sec / elapsed
-        bytes_per_launch = B * dims.n_text_head * 2 * dims.n_audio_ctx * 64 * es      # K and V of every (b, h), read once
+        # bf16 greedy: the cross-attention streams the encoder output itself, 1500 x d elements per window and layer (xattn.hip);
+        # fp32 / beam search: the K and V caches of every (b, h), twice that
+        estream = args.precision == "bf16" and not args.beam and os.environ.get("WX_NO_XATTN") is None
+        bytes_per_launch = B * dims.n_audio_ctx * dims.n_audio_state * es * (1 if estream else 2)
         avg_ms = prof_ms / max(1, prof_n)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if prof_n else 0.0
         # traffic: HBM bytes per launch from a rocprofv3 --pmc pass of THIS command (TCC FETCH_SIZE with the guide's gfx950
         # corrections), committed under profiles/ -- a replayed constant, not something this run measured; other shapes
         # than the default workload's report none
         traffic, traffic_source = None, None
-        for name in ("r02_cross_attn_pmc.json", "r01_cross_attn_pmc.json"):
+        for name in (("r02_estream_pmc.json",) if estream else ("r01_cross_attn_pmc.json",)):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc) and (args.model, B, args.precision) == ("large-v3", 64, "bf16"):
                 try:
@@ -304,14 +307,15 @@ def main():
             "dtype": args.precision, "data": "synthetic",
             "config": {
                 "workload": f"Whisper {args.model} {args.precision} {'beam=%d' % args.beam if args.beam else 'greedy'}, batch {B} x 30 s windows per GPU: "
-                            f"log-mel + encoder + cross-K/V + KV-cache decode"
+                            f"log-mel + encoder + KV-cache decode"
                             + (" (BASELINE.json configs[2])" if (args.model, args.beam, B) == ("large-v3", 0, 64) else ""),
                 "windows_per_gpu": B, "decode_steps_per_window": steps_per_window, "mean_new_tokens": n_tokens,
                 "prompt": "[sot, <|en|>, transcribe, notimestamps]", "weights": "seeded random init (no checkpoints offline)",
                 "hip_graph": not args.no_graph, "parallelism": f"window-dp{world}",
             },
             "roofline": {
-                "kernel": "attn_decode_kernel<bf16,1> (decoder cross-attention)" if es == 2 else "attn_decode_kernel<float>",
+                "kernel": ("xattn_estream_kernel (decoder cross-attention on the encoder output)" if estream else
+                           "attn_decode_kernel (decoder cross-attention over the K/V cache)"),
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms, "launches_timed": prof_n,
@@ -320,10 +324,11 @@ def main():
         # stage rooflines (SURVEY §8d formulas; encoder FLOPs include the cross-K/V projection)
         d_, L_, Ld_, nm_ = dims.n_audio_state, dims.n_audio_layer, dims.n_text_layer, dims.n_mels
         mel_bytes = B * (N_SAMPLES * 4 + 2 * nm_ * N_FRAMES * 4 + nm_ * N_FRAMES * 4)      # stage 1 read+write, stage 2 read+write
-        enc_flop = B * (6 * nm_ * d_ * 3000 + 6 * d_ * d_ * 1500 + L_ * (24 * d_ * d_ * 1500 + 4 * 1500 * 1500 * d_) + 4 * d_ * d_ * 1500 * Ld_)
+        enc_flop = B * (6 * nm_ * d_ * 3000 + 6 * d_ * d_ * 1500 + L_ * (24 * d_ * d_ * 1500 + 4 * 1500 * 1500 * d_)
+                        + (0 if estream else 4 * d_ * d_ * 1500 * Ld_))          # no cross-K/V projection on the E-stream path
         rows = B * max(1, args.beam)
         t_avg = len(prompt) + steps_per_window / 2
-        dec_bytes = (steps_per_window + len(prompt) - 1) * (B * Ld_ * 2 * 1500 * d_ * es + rows * Ld_ * 2 * t_avg * d_ * es
+        dec_bytes = (steps_per_window + len(prompt) - 1) * (B * Ld_ * (1 if estream else 2) * 1500 * d_ * es + rows * Ld_ * 2 * t_avg * d_ * es
                                                              + (16 * d_ * d_ * Ld_ + dims.n_vocab * d_) * es)
         out["stages"] = {
             "mel": {"ms": st_ms[0], "achieved_GBs": mel_bytes / st_ms[0] / 1e6, "peak_GBs": HBM_PEAK_GBS, "bound": "hbm"},

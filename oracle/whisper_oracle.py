@@ -214,7 +214,11 @@ class OracleWhisper:
     conv-stem activations, the encoder output and the cross K/V cache are rounded to bf16 (round-to-nearest-even, what
     ``(bf16)x`` does on the device); every product accumulates in fp32 and the residual stream stays fp32.  The encoder's
     flash kernel also rounds the un-normalised softmax weights to bf16 for the P.V product (the row sum uses the
-    unrounded weights); the decode attention kernels keep them in fp32.  It is the yardstick for the bf16 tolerance:
+    unrounded weights); the decoder's self-attention kernel keeps them in fp32.  The engine's bf16 decoder CROSS-attention
+    works on the encoder output E itself (whisper_amd/csrc/xattn.hip: q~_h = s Wk_h^T bf16(q_h s), scores q~_h . e_j,
+    context c_h = softmax . E, output Wv_h bf16(c_h) + bv -- algebraically the same attention with the key / value
+    projections moved to the query side), so its rounding points are q (bf16), q~ (bf16), the softmax weights (bf16 for
+    the P.E product) and the context (bf16); ``_cross_attention_absorbed`` restates exactly that.  It is the yardstick for the bf16 tolerance:
     what is left between it and the device is summation order -- which bf16 rounding amplifies: two evaluations that
     differ by 1e-6 before a rounding point differ by a whole bf16 ulp after it wherever the rounding flips, and after a few
     layers their distance saturates at the bf16 noise floor of the model.  ``acc_dtype=torch.float64`` gives a second,
@@ -255,6 +259,23 @@ class OracleWhisper:
             out = F.softmax(qk.to(self.dt), dim=-1) @ v
         return self._r(out.permute(0, 2, 1, 3).flatten(start_dim=2))
 
+    def _cross_attention_absorbed(self, h, xa, p, n_head):
+        """bf16-mode decoder cross-attention on the encoder output (the engine's xattn.hip path): ``h [B, t, d]`` the
+        normalised decoder stream, ``xa [B, 1500, d]`` the (bf16-rounded) encoder output."""
+        sd = self.sd
+        B, t, D = h.shape
+        hd = D // n_head
+        s = hd ** -0.25
+        q = self._r((F.linear(h, sd[p + ".query.weight"], sd[p + ".query.bias"]) * s)).view(B, t, n_head, hd)
+        wk = sd[p + ".key.weight"].view(n_head, hd, D)                   # Wk_h: rows h*64 .. of the key projection
+        qt = self._r(torch.einsum("bthc,hcd->bhtd", q, wk) * s)          # q~ [B, H, t, D]
+        sc = qt @ xa.transpose(-1, -2)[:, None]                          # [B, H, t, 1500]
+        pr = torch.exp(sc - sc.amax(dim=-1, keepdim=True))
+        ctx = self._r((self._r(pr) @ xa[:, None]) / pr.sum(dim=-1, keepdim=True))     # [B, H, t, D]
+        wv = sd[p + ".value.weight"].view(n_head, hd, D)
+        out = torch.einsum("bhtd,hcd->bthc", ctx, wv).reshape(B, t, D) + sd[p + ".value.bias"]
+        return self._r(out)
+
     def _lin(self, x, prefix, bias=True):
         return F.linear(x, self.sd[prefix + ".weight"], self.sd[prefix + ".bias"] if bias else None)
 
@@ -285,6 +306,8 @@ class OracleWhisper:
     def cross_kv(self, xa: torch.Tensor):
         """Per decoder layer (K, V) of the encoder output, computed once per window
         (hf:...modeling_whisper.py:311-335 cross-KV reuse)."""
+        if self.bf16:           # the bf16 engine attends the encoder output itself: nothing to project
+            return [xa] * self.dims.n_text_layer
         out = []
         for i in range(self.dims.n_text_layer):
             p = f"decoder.blocks.{i}.cross_attn"
@@ -313,8 +336,11 @@ class OracleWhisper:
                                     dims.n_text_head, mask)
             x = x + self._lin(a, p + ".attn.out")
             h = self._ln(x, p + ".cross_attn_ln")
-            ck, cv = cross[i]
-            a = self._qkv_attention(self._lin(h, p + ".cross_attn.query"), ck, cv, dims.n_text_head)
+            if self.bf16:
+                a = self._cross_attention_absorbed(h, cross[i], p + ".cross_attn", dims.n_text_head)
+            else:
+                ck, cv = cross[i]
+                a = self._qkv_attention(self._lin(h, p + ".cross_attn.query"), ck, cv, dims.n_text_head)
             x = x + self._lin(a, p + ".cross_attn.out")
             x = x + self._mlp(self._ln(x, p + ".mlp_ln"), p)
         x = self._ln(x, "decoder.ln")

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libwhisper_amd.so")
-SOURCES = ["mel.hip", "gemm.hip", "attention.hip", "flash.hip", "elementwise.hip", "beam.hip", "engine.hip"]
+SOURCES = ["mel.hip", "gemm.hip", "attention.hip", "flash.hip", "xattn.hip", "elementwise.hip", "beam.hip", "engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 

@@ -158,6 +158,32 @@ int launch_kv_append(const AttnArgs& a, hipStream_t st);       // prompt pass: w
 int launch_attn_rows(const AttnArgs& a, hipStream_t st);       // many queries, non-causal, dense K/V (fp32 encoder path)
 int launch_attn_flash_bf16(const AttnArgs& a, hipStream_t st); // MFMA flash attention, dense bf16 K/V, non-causal
 
+// ---- decoder cross-attention on the encoder output (xattn.hip) ---------------------------------------------
+struct XQTildeArgs {                     // q~[row][h][:] = s * Wk_h^T bf16((bias + sum of split-K tiles) * s)
+    const float* q_partial = nullptr; const float* q_bias = nullptr; int q_nsplit = 0;   // [split][rows][d] tiles of the query projection
+    const bf16* WkT = nullptr;           // [d][d]: cross-attention key weight TRANSPOSED (row i, column h*64 + c)
+    bf16* qt = nullptr;                  // [rows][H][d]
+    float scale = 1.f;                   // head_dim^-0.25
+    int rows = 0, H = 0, d = 0;
+};
+struct XAttnArgs {                       // one workgroup per (row, key split)
+    const bf16* qt = nullptr;            // [rows][H][d]
+    const bf16* E = nullptr;             // encoder output [windows][T][d]; row r attends window r / group
+    bf16* cpart = nullptr;               // [rows][n_split][H][d]: context of the split's keys, normalised by the split's own sum
+    float* ml = nullptr;                 // [rows][n_split][H][2]: running maximum and sum of the split
+    int rows = 0, H = 0, d = 0, T = 0, group = 1, n_split = 1;
+};
+struct XCProjArgs {                      // out[row][h*64 + c] = bv + Wv_h . bf16(sum_s w_s cpart_s)
+    const bf16* cpart = nullptr; const float* ml = nullptr; int n_split = 1;
+    const bf16* Wv = nullptr;            // [d][d] cross-attention value weight (row h*64 + c)
+    const float* bv = nullptr;           // [d]
+    bf16* out = nullptr; int64_t ldo = 0;
+    int rows = 0, H = 0, d = 0;
+};
+int launch_xattn_qtilde(const XQTildeArgs& a, hipStream_t st);
+int launch_xattn_estream(const XAttnArgs& a, hipStream_t st);
+int launch_xattn_cproj(const XCProjArgs& a, hipStream_t st);
+
 // ---- sampler ------------------------------------------------------------------------------------------
 struct SamplerArgs {
     const float* logits = nullptr; int64_t ldl = 0; int n_vocab = 0;

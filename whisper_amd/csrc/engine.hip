@@ -40,6 +40,7 @@ struct LayerW {
     float *lnx_g = nullptr, *lnx_b = nullptr;      // cross-attention LN (decoder only)
     void* xq = nullptr; float* xbq = nullptr;      // cross query
     void* xkv = nullptr; float* xbkv = nullptr;    // fused cross key|value
+    void* xk_t = nullptr;                          // bf16 engines: cross key weight TRANSPOSED [d in][d out] (xattn.hip)
     void* xo = nullptr; float* xbo = nullptr;
     float *ln2_g = nullptr, *ln2_b = nullptr;
     void* w1 = nullptr; float* b1 = nullptr; void* w2 = nullptr; float* b2 = nullptr;
@@ -83,6 +84,11 @@ struct wx_engine {
     int32_t *row_n_prompt = nullptr, *row_sot = nullptr;      // per-row prompt length / SOT position
     uint32_t* dyn = nullptr;                                 // {temperature bits, seed, sample_len} read by the sampler
     float *sum_logprob = nullptr, *no_speech = nullptr, *partial = nullptr, *gpartial = nullptr, *samp_part = nullptr;
+    // decoder cross-attention on the encoder output (xattn.hip; bf16 engines, every row whose window has no beams to share with)
+    bool xattn = false;
+    int x_split = 1;                                         // key splits per row: a function of max_batch only (batch invariance)
+    void *x_qt = nullptr, *x_cpart = nullptr; float* x_ml = nullptr;
+    int cross_kv_B = 0;                                      // windows whose K/V cache matches the last wx_encode (lazy: beams, > 80 rows)
     int32_t* h_pinned = nullptr;
     float* static_scratch = nullptr;                         // this device's address of the file-scope `scratch` array (wx_log_mel_static)
     float* rs_taps = nullptr;                                // resampler taps (wx_resample_pcm16), RS_MAX_TAPS floats
@@ -299,6 +305,7 @@ int wx_create(const wx_config* cfg, wx_engine** out) {
     e->n_pages_seq = c.n_text_ctx / KV_PAGE;
     e->ld_tok = c.n_text_ctx + 1;
     e->qk_scale = powf((float)HEAD_DIM, -0.25f);
+    e->xattn = e->dt == DT_BF16 && getenv("WX_NO_XATTN") == nullptr;
     hipError_t r = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
     if (r == hipSuccess) r = hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming);
     if (r == hipSuccess) r = hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming);
@@ -404,6 +411,12 @@ int wx_finalize(wx_engine* e) {
             if ((r = upload_w(e, q->data.data(), q->data.size(), &L.xq))) return r;
             if ((r = upload_f32(e, qb->data.data(), d, &L.xbq))) return r;
             if ((r = upload_w(e, kv.data(), kv.size(), &L.xkv))) return r;
+            if (e->xattn) {
+                std::vector<float> kt((size_t)d * d);
+                for (int o = 0; o < d; ++o)
+                    for (int in = 0; in < d; ++in) kt[(size_t)in * d + o] = k->data[(size_t)o * d + in];
+                if ((r = upload_w(e, kt.data(), kt.size(), &L.xk_t))) return r;
+            }
             if ((r = upload_f32(e, kvb.data(), kvb.size(), &L.xbkv))) return r;
             if ((r = upload_w(e, o->data.data(), o->data.size(), &L.xo))) return r;
             if ((r = upload_f32(e, ob->data.data(), d, &L.xbo))) return r;
@@ -475,9 +488,17 @@ int wx_finalize(wx_engine* e) {
     if ((r = A(&e->att, (size_t)rows * d * es))) return r;
     if ((r = A(&e->hid, (size_t)rows * 4 * d * es))) return r;
     if ((r = A(&e->enc_out, (size_t)rows * d * es))) return r;
-    const size_t cross_layer = (size_t)B * e->Ht * T * HEAD_DIM;
-    if ((r = A(&e->crossK, cross_layer * c.n_text_layer * es))) return r;
-    if ((r = A(&e->crossV, cross_layer * c.n_text_layer * es))) return r;
+    if (!e->xattn) {       // xattn engines attend the encoder output itself; their K/V cache is built on first need (ensure_cross_kv)
+        const size_t cross_layer = (size_t)B * e->Ht * T * HEAD_DIM;
+        if ((r = A(&e->crossK, cross_layer * c.n_text_layer * es))) return r;
+        if ((r = A(&e->crossV, cross_layer * c.n_text_layer * es))) return r;
+    } else {
+        e->x_split = 1;
+        while (e->x_split < 8 && B * e->x_split < 256) e->x_split *= 2;
+        if ((r = A(&e->x_qt, (size_t)B * e->Ht * d * 2))) return r;
+        if ((r = A(&e->x_cpart, (size_t)B * e->x_split * e->Ht * d * 2))) return r;
+        if ((r = A((void**)&e->x_ml, (size_t)B * e->x_split * e->Ht * 2 * 4))) return r;
+    }
     const size_t self_layer = (size_t)B * e->n_pages_seq * e->Ht * KV_PAGE * HEAD_DIM;
     if ((r = A(&e->selfK, self_layer * c.n_text_layer * es))) return r;
     if ((r = A(&e->selfV, self_layer * c.n_text_layer * es))) return r;
@@ -619,6 +640,37 @@ static int encoder_attention(wx_engine* e, int B, hipStream_t st) {
     return launch_attn_rows(a, st);
 }
 
+// cross-attention K/V of every decoder layer for the B windows of the last encode (k pre-scaled by head_dim^-0.25)
+static int project_cross_kv(wx_engine* e, int B, hipStream_t st) {
+    const int d = e->d, T = e->T, dtp = e->dt, M = B * T;
+    const size_t es = dtype_size(dtp);
+    const size_t cross_layer = (size_t)e->cfg.max_batch * e->Ht * T * HEAD_DIM;
+    if (!e->crossK) {      // xattn engines: first use (beam search at width > 1, or more rows than the split-K decode path takes)
+        int r;
+        if ((r = dev_alloc(e, &e->crossK, cross_layer * e->cfg.n_text_layer * es, false))) return r;
+        if ((r = dev_alloc(e, &e->crossV, cross_layer * e->cfg.n_text_layer * es, false))) return r;
+    }
+    for (int i = 0; i < e->cfg.n_text_layer; ++i) {
+        const LayerW& L = e->dec[i];
+        GemmArgs g = gemm_basic(e, e->enc_out, d, L.xkv, M, 2 * d, d);
+        g.ep.bias = L.xbkv; g.ep.colscale_period = d; g.ep.colscale[0] = e->qk_scale;
+        g.ep.mode = 1; g.ep.out_dtype = dtp; g.ep.hs_T = T; g.ep.hs_H = e->Ht; g.ep.hs_d = d;
+        g.ep.out_split[0] = (char*)e->crossK + cross_layer * i * es; g.ep.out_split[1] = (char*)e->crossV + cross_layer * i * es;
+        WX_TRY(launch_gemm(g, st));
+    }
+    e->cross_kv_B = B;
+    return 0;
+}
+
+// The K/V-cache kernels serve: every fp32 engine; on bf16 engines beam search at width > 1 (the beams of a window share one
+// K/V stream) and batches beyond the split-K decode path.  Must be called outside graph capture (it may allocate).
+static int ensure_cross_kv(wx_engine* e, int rows, int beam_n, hipStream_t st) {
+    if (!e->xattn) return 0;                                   // projected by wx_encode
+    if (beam_n <= 1 && rows <= DG_MAX_ROWS) return 0;          // the E-stream path needs no K/V
+    if (e->cross_kv_B >= e->encoded_B && e->crossK) return 0;
+    return project_cross_kv(e, e->encoded_B, st);
+}
+
 int wx_encode(wx_engine* e, const float* d_mel, int64_t win_stride, int64_t row_stride, int64_t n_valid_frames, int32_t B,
               void* stream) {
     if (!e || !e->finalized) return fail(WX_ERR_STATE, "engine not finalized");
@@ -675,17 +727,9 @@ int wx_encode(wx_engine* e, const float* d_mel, int64_t win_stride, int64_t row_
         }
     }
     WX_TRY(launch_layernorm(e->x, e->lnpost_g, e->lnpost_b, e->enc_out, dtp, M, d, st));
-    // cross-attention K/V of every decoder layer, once per window (k pre-scaled by head_dim^-0.25)
-    const size_t cross_layer = (size_t)e->cfg.max_batch * e->Ht * T * HEAD_DIM;
-    for (int i = 0; i < e->cfg.n_text_layer; ++i) {
-        const LayerW& L = e->dec[i];
-        GemmArgs g = gemm_basic(e, e->enc_out, d, L.xkv, M, 2 * d, d);
-        g.ep.bias = L.xbkv; g.ep.colscale_period = d; g.ep.colscale[0] = e->qk_scale;
-        g.ep.mode = 1; g.ep.out_dtype = dtp; g.ep.hs_T = T; g.ep.hs_H = e->Ht; g.ep.hs_d = d;
-        g.ep.out_split[0] = (char*)e->crossK + cross_layer * i * es; g.ep.out_split[1] = (char*)e->crossV + cross_layer * i * es;
-        WX_TRY(launch_gemm(g, st));
-    }
+    e->cross_kv_B = 0;
     e->encoded_B = B;
+    if (!e->xattn) return project_cross_kv(e, B, st);
     return WX_OK;
 }
 
@@ -849,13 +893,30 @@ static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, floa
         WX_TRY(split_gemm(datt, d, L.self.wo, L.self.wo_pk, d, s_dd));
         WX_TRY(launch_reduce_layernorm(dx, gpartial, s_dd, L.self.bo, L.lnx_g, L.lnx_b, dxn, dtp, B, d, st));
         WX_TRY(split_gemm(dxn, d, L.xq, L.xq_pk, d, s_dd));
-        {
+        const bool prof = prof_ok && e->prof_on && e->prof_used + 2 <= e->prof_events.size();
+        if (e->xattn && e->beam_n <= 1) {
+            // cross-attention on the encoder output itself (xattn.hip): q~ = s Wk_h^T q_h, one stream over E per row for
+            // all heads, then the value projection of the context vectors.  Row r attends window (b0 + r) / G.
+            XQTildeArgs qa;
+            qa.q_partial = gpartial; qa.q_bias = L.xbq; qa.q_nsplit = s_dd; qa.WkT = (const bf16*)L.xk_t; qa.qt = (bf16*)e->x_qt;
+            qa.scale = e->qk_scale; qa.rows = B; qa.H = e->Ht; qa.d = d;
+            WX_TRY(launch_xattn_qtilde(qa, st));
+            XAttnArgs xa;
+            xa.qt = (const bf16*)e->x_qt; xa.E = (const bf16*)e->enc_out + (size_t)(b0 / G) * T * d; xa.cpart = (bf16*)e->x_cpart; xa.ml = e->x_ml;
+            xa.rows = B; xa.H = e->Ht; xa.d = d; xa.T = T; xa.group = G; xa.n_split = e->x_split;
+            if (prof) HIP_TRY(hipEventRecord(e->prof_events[e->prof_used], st));
+            WX_TRY(launch_xattn_estream(xa, st));
+            if (prof) { HIP_TRY(hipEventRecord(e->prof_events[e->prof_used + 1], st)); e->prof_used += 2; }
+            XCProjArgs ca;
+            ca.cpart = (const bf16*)e->x_cpart; ca.ml = e->x_ml; ca.n_split = e->x_split;
+            ca.Wv = (const bf16*)L.xkv + (size_t)d * d; ca.bv = L.xbkv + d; ca.out = (bf16*)datt; ca.ldo = d; ca.rows = B; ca.H = e->Ht; ca.d = d;
+            WX_TRY(launch_xattn_cproj(ca, st));
+        } else {
             AttnArgs a;
             a.dt = dtp; a.q_partial = gpartial; a.q_bias = L.xbq; a.q_nsplit = s_dd; a.q_scale = e->qk_scale; a.q_sb = d; a.n_q = 1;
             a.K = (char*)e->crossK + (cross_layer * i + cross_b0) * es; a.V = (char*)e->crossV + (cross_layer * i + cross_b0) * es;
             a.kv_sbh = (int64_t)T * HEAD_DIM; a.n_keys = T; a.kv_group = e->beam_n > 0 ? e->beam_n : G;
             a.O = datt; a.o_sb = d; a.B = B; a.H = e->Ht; a.n_split = n_split; a.partial = apartial;
-            const bool prof = prof_ok && e->prof_on && e->prof_used + 2 <= e->prof_events.size();
             if (prof) HIP_TRY(hipEventRecord(e->prof_events[e->prof_used], st));
             WX_TRY(launch_attn_decode(a, st));
             if (prof) { HIP_TRY(hipEventRecord(e->prof_events[e->prof_used + 1], st)); e->prof_used += 2; }
@@ -953,6 +1014,7 @@ static int decode_rows_impl(wx_engine* e, int32_t B, const int32_t* h_rows, cons
     if (o.check_interval < 1) o.check_interval = 8;
     StreamScope sc(e, stream);
     hipStream_t st = sc.st;
+    if (int rk = ensure_cross_kv(e, B, 0, st)) return rk;
     // initial state
     {
         std::vector<int32_t> rows((size_t)B * e->ld_tok, c.tok_eot);
@@ -1105,6 +1167,7 @@ int wx_decode_beam(wx_engine* e, int32_t B, int32_t beam_size, int32_t max_candi
     if (o.check_interval < 1) o.check_interval = 8;
     StreamScope sc(e, stream);
     hipStream_t st = sc.st;
+    if (int rk = ensure_cross_kv(e, R, n, st)) return rk;
     e->beam_n = n;
     {
         std::vector<int32_t> rows((size_t)R * e->ld_tok, c.tok_eot), node((size_t)R * c.n_text_ctx, 0);
@@ -1198,6 +1261,7 @@ int wx_decoder_logits(wx_engine* e, int32_t B, const int32_t* d_tokens, int32_t 
     e->beam_n = 0;
     StreamScope sc(e, stream);
     hipStream_t st = sc.st;
+    if (int rk = ensure_cross_kv(e, B, 0, st)) return rk;
     HIP_TRY(hipMemcpy2DAsync(e->tokens, (size_t)e->ld_tok * 4, d_tokens, (size_t)n * 4, (size_t)n * 4, B, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemsetAsync(e->d_pos, 0, 64, st));
     wx_decode_opts o{};
