@@ -31,7 +31,14 @@ int main(int argc, char** argv) {
     const float scale = powf(64.f, -0.25f);
     hipStream_t st; CK(hipStreamCreate(&st));
     const size_t e_elems = (size_t)rows * T * d;
-    bf16* E[2]; for (int i = 0; i < 2; ++i) { CK(hipMalloc(&E[i], e_elems * 2)); hipLaunchKernelGGL(fill_bf16, dim3(4096), dim3(256), 0, st, E[i], e_elems, 1.0f, 17u + i); }
+    const int nt16 = ((T + 15) / 16 + 1) / 2 * 2;
+    const size_t f_elems = (size_t)rows * nt16 * 16 * d;
+    bf16 *E[2], *Ef[2];
+    for (int i = 0; i < 2; ++i) {
+        CK(hipMalloc(&E[i], e_elems * 2)); CK(hipMalloc(&Ef[i], f_elems * 2));
+        hipLaunchKernelGGL(fill_bf16, dim3(4096), dim3(256), 0, st, E[i], e_elems, 1.0f, 17u + i);
+        if (launch_xattn_pack_e(E[i], Ef[i], rows, T, d, nt16, st)) { printf("pack failed\n"); return 1; }
+    }
     bf16 *WkT, *Wv, *qt, *cpart, *att; float *qpart, *qbias, *bv, *ml;
     CK(hipMalloc(&WkT, (size_t)d * d * 2)); CK(hipMalloc(&Wv, (size_t)d * d * 2));
     hipLaunchKernelGGL(fill_bf16, dim3(1024), dim3(256), 0, st, WkT, (size_t)d * d, 0.05f, 3u);
@@ -43,7 +50,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&att, (size_t)rows * d * 2));
     CK(hipStreamSynchronize(st));
     XQTildeArgs qa; qa.q_partial = qpart; qa.q_bias = qbias; qa.q_nsplit = NSQ; qa.WkT = WkT; qa.qt = qt; qa.scale = scale; qa.rows = rows; qa.H = H; qa.d = d;
-    XAttnArgs xa; xa.qt = qt; xa.E = E[0]; xa.cpart = cpart; xa.ml = ml; xa.rows = rows; xa.H = H; xa.d = d; xa.T = T; xa.group = 1; xa.n_split = S;
+    XAttnArgs xa; xa.nt16 = nt16; xa.qt = qt; xa.E = Ef[0]; xa.cpart = cpart; xa.ml = ml; xa.rows = rows; xa.H = H; xa.d = d; xa.T = T; xa.group = 1; xa.n_split = S;
     XCProjArgs ca; ca.cpart = cpart; ca.ml = ml; ca.n_split = S; ca.Wv = Wv; ca.bv = bv; ca.out = att; ca.ldo = d; ca.rows = rows; ca.H = H; ca.d = d;
     if (launch_xattn_qtilde(qa, st) || launch_xattn_estream(xa, st) || launch_xattn_cproj(ca, st)) { printf("launch failed\n"); return 1; }
     CK(hipStreamSynchronize(st));
@@ -87,7 +94,7 @@ int main(int argc, char** argv) {
         hipGraph_t g; hipGraphExec_t ge;
         CK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
         for (int l = 0; l < L; ++l) {
-            xa.E = E[l & 1];
+            xa.E = Ef[l & 1];
             int rc = 0;
             if (which == 0 || which == 3) rc |= launch_xattn_qtilde(qa, st);
             if (which == 1 || which == 3) rc |= launch_xattn_estream(xa, st);

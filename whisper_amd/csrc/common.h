@@ -168,10 +168,12 @@ struct XQTildeArgs {                     // q~[row][h][:] = s * Wk_h^T bf16((bia
 };
 struct XAttnArgs {                       // one workgroup per (row, key split)
     const bf16* qt = nullptr;            // [rows][H][d]
-    const bf16* E = nullptr;             // encoder output [windows][T][d]; row r attends window r / group
+    const bf16* E = nullptr;             // encoder output in MFMA-fragment order [windows][nt16][d/32][64][8] (launch_xattn_pack_e);
+                                         // row r attends window r / group
     bf16* cpart = nullptr;               // [rows][n_split][H][d]: context of the split's keys, normalised by the split's own sum
     float* ml = nullptr;                 // [rows][n_split][H][2]: running maximum and sum of the split
     int rows = 0, H = 0, d = 0, T = 0, group = 1, n_split = 1;
+    int nt16 = 0;                        // 16-key tiles stored per window: even, >= ceil(T / 16)
 };
 struct XCProjArgs {                      // out[row][h*64 + c] = bv + Wv_h . bf16(sum_s w_s cpart_s)
     const bf16* cpart = nullptr; const float* ml = nullptr; int n_split = 1;
@@ -180,6 +182,7 @@ struct XCProjArgs {                      // out[row][h*64 + c] = bv + Wv_h . bf1
     bf16* out = nullptr; int64_t ldo = 0;
     int rows = 0, H = 0, d = 0;
 };
+int launch_xattn_pack_e(const void* E, void* Ef, int windows, int T, int D, int nt16, hipStream_t st);
 int launch_xattn_qtilde(const XQTildeArgs& a, hipStream_t st);
 int launch_xattn_estream(const XAttnArgs& a, hipStream_t st);
 int launch_xattn_cproj(const XCProjArgs& a, hipStream_t st);

@@ -87,6 +87,8 @@ struct wx_engine {
     // decoder cross-attention on the encoder output (xattn.hip; bf16 engines, every row whose window has no beams to share with)
     bool xattn = false;
     int x_split = 1;                                         // key splits per row: a function of max_batch only (batch invariance)
+    void* enc_frag = nullptr;                                // encoder output in MFMA-fragment order [windows][x_nt16][d / 32][64][8] bf16
+    int x_nt16 = 0;                                          // 16-key tiles per window in enc_frag (even; zero rows past T)
     void *x_qt = nullptr, *x_cpart = nullptr; float* x_ml = nullptr;
     int cross_kv_B = 0;                                      // windows whose K/V cache matches the last wx_encode (lazy: beams, > 80 rows)
     int32_t* h_pinned = nullptr;
@@ -495,6 +497,8 @@ int wx_finalize(wx_engine* e) {
     } else {
         e->x_split = 1;
         while (e->x_split < 8 && B * e->x_split < 256) e->x_split *= 2;
+        e->x_nt16 = ((T + 15) / 16 + 1) / 2 * 2;
+        if ((r = A(&e->enc_frag, (size_t)B * e->x_nt16 * 16 * d * 2))) return r;
         if ((r = A(&e->x_qt, (size_t)B * e->Ht * d * 2))) return r;
         if ((r = A(&e->x_cpart, (size_t)B * e->x_split * e->Ht * d * 2))) return r;
         if ((r = A((void**)&e->x_ml, (size_t)B * e->x_split * e->Ht * 2 * 4))) return r;
@@ -730,6 +734,7 @@ int wx_encode(wx_engine* e, const float* d_mel, int64_t win_stride, int64_t row_
     e->cross_kv_B = 0;
     e->encoded_B = B;
     if (!e->xattn) return project_cross_kv(e, B, st);
+    WX_TRY(launch_xattn_pack_e(e->enc_out, e->enc_frag, B, e->T, d, e->x_nt16, st));
     return WX_OK;
 }
 
@@ -902,7 +907,7 @@ static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, floa
             qa.scale = e->qk_scale; qa.rows = B; qa.H = e->Ht; qa.d = d;
             WX_TRY(launch_xattn_qtilde(qa, st));
             XAttnArgs xa;
-            xa.qt = (const bf16*)e->x_qt; xa.E = (const bf16*)e->enc_out + (size_t)(b0 / G) * T * d; xa.cpart = (bf16*)e->x_cpart; xa.ml = e->x_ml;
+            xa.qt = (const bf16*)e->x_qt; xa.E = (const bf16*)e->enc_frag + (size_t)(b0 / G) * e->x_nt16 * 16 * d; xa.nt16 = e->x_nt16; xa.cpart = (bf16*)e->x_cpart; xa.ml = e->x_ml;
             xa.rows = B; xa.H = e->Ht; xa.d = d; xa.T = T; xa.group = G; xa.n_split = e->x_split;
             if (prof) HIP_TRY(hipEventRecord(e->prof_events[e->prof_used], st));
             WX_TRY(launch_xattn_estream(xa, st));

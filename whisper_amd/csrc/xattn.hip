@@ -27,109 +27,118 @@ namespace wx {
 typedef __attribute__((ext_vector_type(4))) short i16x4;
 typedef __attribute__((ext_vector_type(8))) short i16x8;
 constexpr float XA_LOG2E = 1.4426950408889634f;
-#ifndef XA_VARIANT
-#define XA_VARIANT 0                                // diagnostics (tools/mb_xattn.sh): 1 = staging only, no S / softmax / C phases
-#endif
+#ifndef XA_SKIP
+#define XA_SKIP 0                                   // diagnostics (tools/mb_xattn.sh), bit mask of the parts left out of the E-stream kernel: 1 = S product,
+#endif                                              // 2 = global loads inside the loop, 4 = C phase, 8 = softmax, 16 = image write
 constexpr int XA_KT = 32;                          // keys per tile (one MFMA k-step of the P·E product)
 
 // ---------------------------------------------------------------------------------------------------------
-// E-stream attention.  8 waves.
-//   S phase   wave (qtile, kpart): Sᵀ[32 keys][16 queries] partial over its d / KSPLIT slice of the width (both 16-key
-//             halves, so no two waves hold the same q̃ fragments), A operand = E rows (ds_read_b128), B operand = q̃
-//             (registers, loaded once); the partial tiles meet in LDS.
-//   softmax   every wave redundantly (same values, same order): query on the lane, 8 keys per lane and query tile.
-//   C phase   wave w owns the 16-wide column tiles [w·D/128, (w+1)·D/128) of c: Cᵀ[i][q] += E[key][i]ᵀ · Pᵀ, A operand =
-//             Eᵀ via ds_read_b64_tr_b16 from the same image, B operand = the S accumulators converted in place.
-// LDS image: 32 rows of D bf16 at a pitch of 2D + 32 bytes (conflict-free for both kinds of read).
+// E-stream attention.  8 waves, tiles of 32 keys, three barriers per tile.
+//   E arrives in MFMA-FRAGMENT ORDER (xattn_pack_e_kernel: [window][16-key tile][k-step][lane][8]: lane (g, r) of block
+//   (kt, ks) holds E[16 kt + r][32 ks + 8g .. +8], zero beyond the last key), so a wave's 16-B-per-lane load is 1 KiB
+//   contiguous AND already the A operand of the S product:
+//   S phase   wave w takes the k-steps [w KSW, (w+1) KSW) of the width for both 16-key halves and all query tiles,
+//             straight from the registers its loads landed in (B operand = q~, registers, loaded once); the same
+//             registers go to the row-major LDS image for the C phase.  Partial S tiles meet in LDS.
+//   softmax   wave qt < NQT sums the partials of query tile qt in a fixed order, runs the online softmax (query on the
+//             lane, 8 keys per lane) and publishes P (bf16, already in B-operand order) and the rescale factor.
+//   C phase   wave w owns the 16-wide column tiles [w D/128, (w+1) D/128) of c: C^T[i][q] += E[key][i]^T . P^T, A operand =
+//             E^T via ds_read_b64_tr_b16 from the image (pitch 2D + 32 bytes: conflict-free), B operand = P from LDS.
+//   Two register sets: the loads of tile t + 2 are issued as soon as tile t's fragments are consumed.
 // ---------------------------------------------------------------------------------------------------------
 template <int D, int NQT>
 __global__ __launch_bounds__(512) void xattn_estream_kernel(XAttnArgs a) {
     constexpr int PITCH = D * 2 + 32;
-    constexpr int KSPLIT = ((D / 32) % (8 / NQT) == 0) ? 8 / NQT : 4 / NQT;      // waves past NQT * KSPLIT sit the S phase out
-    constexpr int KSLICE = D / KSPLIT, KSTEPS = KSLICE / 32;
-    constexpr int CPT = D / 128;                   // 16-B chunks staged per thread and tile (32 rows x D/8 chunks / 512)
-    constexpr int ITW = D / 128;                   // 16-wide column tiles of c per wave
+    constexpr int KS_ALL = D / 32;
+    constexpr int NSW = (KS_ALL % 8 == 0) ? 8 : 4;             // waves that take part in the S phase (d = 384: 4 x 3 k-steps)
+    constexpr int KSW = KS_ALL / NSW;                          // k-steps per S wave
+    constexpr int ITW = D / 128;                               // 16-wide column tiles of c per wave
     __shared__ __attribute__((aligned(16))) char img[XA_KT * PITCH];
-    __shared__ __attribute__((aligned(16))) char qimg[(D / 64 + 1) * PITCH];          // H + 1 rows (H = D / 64)
-    __shared__ __attribute__((aligned(16))) f32x4 sbuf[KSPLIT * NQT * 2 * 64];     // [kpart][qtile][key half][lane]
+    __shared__ __attribute__((aligned(16))) f32x4 sbuf[NSW * NQT * 2 * 64];        // [S wave][query tile][key half][lane]
+    __shared__ __attribute__((aligned(16))) bf16x8 pbuf[NQT * 64];
+    __shared__ float abuf[NQT * 16], lbuf[NQT * 16];
     const int row = blockIdx.x / a.n_split, split = blockIdx.x % a.n_split;
     const int win = row / a.group;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, r = lane & 15;
-    const int qtile = wid % NQT, kpart = wid / NQT;
-    const bool s_role = kpart < KSPLIT;
+    const bool s_role = NSW == 8 || wid < NSW;                 // wave-uniform
+    const int kw = s_role ? wid : 0;
     const int T = a.T, H = a.H;
 
-    // q~ of this row: [H][D] into LDS once (+ one zero row that the padding queries H .. 16 NQT - 1 read); the S phase
-    // takes its B fragments from there (in registers they cost 40 VGPRs at d = 1280, which the two staging sets need)
-    for (int id = tid; id < (H + 1) * (D / 8); id += 512) {
-        const int q = id / (D / 8), c = id % (D / 8);
-        bf16x8 v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        if (q < H) v = *reinterpret_cast<const bf16x8*>(a.qt + ((int64_t)row * H + q) * D + c * 8);
-        *reinterpret_cast<bf16x8*>(qimg + q * PITCH + c * 16) = v;
-    }
-    const int qrow = qtile * 16 + r < H ? qtile * 16 + r : H;
-    const int nt = (T + XA_KT - 1) / XA_KT;
-    const int t0 = (int)((int64_t)split * nt / a.n_split), t1 = (int)((int64_t)(split + 1) * nt / a.n_split);
-    // staging map: thread -> row tid >> 4 of the tile, 16-B chunks (tid & 15) + 16 k: one address per thread and tile, the
-    // rest are compile-time offsets.  TWO register sets: the loads of tile t + 2 are issued as soon as tile t has gone to
-    // LDS, so a CU always has one to two tiles (80-160 KB at d = 1280) in flight instead of an empty queue after every tile.
-    const int srow = tid >> 4, scs = tid & 15;
-    const bf16* Eb = a.E + (int64_t)win * T * D + scs * 8;
-    char* sdst = img + srow * PITCH + scs * 16;
-    bf16x8 stA[CPT], stB[CPT];
-    auto load_tile = [&](bf16x8 (&st)[CPT], int t) {
-        int key = t * XA_KT + srow; if (key > T - 1) key = T - 1;
-        const bf16* src = Eb + (int64_t)key * D;
+    bf16x8 qf[NQT][KSW];
 #pragma unroll
-        for (int p = 0; p < CPT; ++p) st[p] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(src + p * 128));
+    for (int qt = 0; qt < NQT; ++qt) {
+        const int q = qt * 16 + r;
+        const bf16* qp = a.qt + ((int64_t)row * H + (q < H ? q : H - 1)) * D + kw * KSW * 32 + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KSW; ++ks) {
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(qp + ks * 32);
+            if (q >= H) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            qf[qt][ks] = v;
+        }
+    }
+    const int nt = a.nt16 / 2;
+    const int t0 = (int)((int64_t)split * nt / a.n_split), t1 = (int)((int64_t)(split + 1) * nt / a.n_split);
+    // Buffer loads: a tile index past this split's range turns into an offset past the window's records, which the range check
+    // drops (zeros, no traffic).  The loads are therefore UNCONDITIONAL, and the compiler's wait counts stay exact: with the loads
+    // under a branch it has to drain every outstanding load at the top of a tile (vmcnt(0)), which serialises the two register sets.
+    const __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16*>(a.E) + (int64_t)win * a.nt16 * KS_ALL * 512, 0, a.nt16 * KS_ALL * 1024, 0x00020000);
+    const uint32_t voff0 = (uint32_t)(kw * KSW * 1024 + lane * 16);
+    char* sdst = img + r * PITCH + (kw * KSW * 32 + g * 8) * 2;
+    bf16x8 stA[2][KSW], stB[2][KSW];
+    auto load_tile = [&](bf16x8 (&st)[2][KSW], int t) {
+        const uint32_t vo = (s_role && t < t1) ? voff0 + (uint32_t)t * (2 * KS_ALL * 1024) : 0x80000000u;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int ks = 0; ks < KSW; ++ks)
+                st[hh][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ers, vo, (hh * KS_ALL + ks) * 1024, 2));
     };
     f32x4 accC[ITW][NQT];
 #pragma unroll
     for (int it = 0; it < ITW; ++it)
 #pragma unroll
         for (int qt = 0; qt < NQT; ++qt) accC[it][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run[NQT], l_run[NQT];
-#pragma unroll
-    for (int qt = 0; qt < NQT; ++qt) { m_run[qt] = -INFINITY; l_run[qt] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;                      // softmax waves only: query tile wid
 
-    if (t0 < t1) load_tile(stA, t0);
-    if (t0 + 1 < t1) load_tile(stB, t0 + 1);
-    auto tile_body = [&](bf16x8 (&st)[CPT], int t) {
+    load_tile(stA, t0);
+    __builtin_amdgcn_sched_barrier(0);                         // issue order = consumption order, or the first wait in the loop has to be vmcnt(0)
+    load_tile(stB, t0 + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    auto tile_body = [&](bf16x8 (&st)[2][KSW], int t) {
+        if (s_role) {
+            // fragments -> image (for the transposed reads of the C phase) and, from the same registers, the S product
+#if !(XA_SKIP & 16)
 #pragma unroll
-        for (int p = 0; p < CPT; ++p) *reinterpret_cast<bf16x8*>(sdst + p * 256) = st[p];
-        __syncthreads();
-        if (t + 2 < t1) load_tile(st, t + 2);
-#if XA_VARIANT == 1
-        __syncthreads();
-        return;
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int ks = 0; ks < KSW; ++ks) *reinterpret_cast<bf16x8*>(sdst + hh * 16 * PITCH + ks * 64) = st[hh][ks];
 #endif
-        // ---- S phase -----------------------------------------------------------------------------------------
-        if (s_role) {                                               // wave-uniform
-            f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-            const char* ap = img + r * PITCH + (kpart * KSLICE + g * 8) * 2;
-            const char* qp = qimg + qrow * PITCH + (kpart * KSLICE + g * 8) * 2;
+#if !(XA_SKIP & 1)
 #pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) {
-                const bf16x8 e0 = *reinterpret_cast<const bf16x8*>(ap + ks * 64);
-                const bf16x8 e1 = *reinterpret_cast<const bf16x8*>(ap + ks * 64 + 16 * PITCH);
-                const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qp + ks * 64);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(e0, qf, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(e1, qf, acc1, 0, 0, 0);
-            }
-            sbuf[((kpart * NQT + qtile) * 2 + 0) * 64 + lane] = acc0;
-            sbuf[((kpart * NQT + qtile) * 2 + 1) * 64 + lane] = acc1;
+            for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KSW; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st[hh][ks], qf[qt][ks], acc, 0, 0, 0);
+                    sbuf[((wid * NQT + qt) * 2 + hh) * 64 + lane] = acc;
+                }
+#endif
         }
         __syncthreads();
-        // ---- online softmax: lane (g, r) holds keys 4g..4g+3 of both 16-key halves for query r of each query tile --------
-        bf16x8 pf[NQT];
-#pragma unroll
-        for (int qt = 0; qt < NQT; ++qt) {
+#if !(XA_SKIP & 2)
+        load_tile(st, t + 2);
+#endif
+        // ---- online softmax of query tile wid: lane (g, r) holds keys 4g..4g+3 of both 16-key halves for query r ------------
+#if !(XA_SKIP & 8)
+        if (wid < NQT) {
             f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
 #pragma unroll
-            for (int kp = 0; kp < KSPLIT; ++kp) {               // fixed order: the K slices in ascending order
-                s0 += sbuf[((kp * NQT + qt) * 2 + 0) * 64 + lane];
-                s1 += sbuf[((kp * NQT + qt) * 2 + 1) * 64 + lane];
+            for (int w = 0; w < NSW; ++w) {                     // fixed order: the K slices in ascending order
+                s0 += sbuf[((w * NQT + wid) * 2 + 0) * 64 + lane];
+                s1 += sbuf[((w * NQT + wid) * 2 + 1) * 64 + lane];
             }
             if ((t + 1) * XA_KT > T) {                          // only the last tile of the window can run past the keys
 #pragma unroll
@@ -141,8 +150,8 @@ __global__ __launch_bounds__(512) void xattn_estream_kernel(XAttnArgs a) {
             float mt = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
             mt = fmaxf(mt, __shfl_xor(mt, 16));
             mt = fmaxf(mt, __shfl_xor(mt, 32));
-            const float mn = fmaxf(m_run[qt], mt);
-            const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - mn) * XA_LOG2E);
+            const float mn = fmaxf(m_run, mt);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - mn) * XA_LOG2E);
             const float mn2 = mn * XA_LOG2E;
             float p[8];
 #pragma unroll
@@ -150,17 +159,29 @@ __global__ __launch_bounds__(512) void xattn_estream_kernel(XAttnArgs a) {
                 p[j] = __builtin_amdgcn_exp2f(fmaf(s0[j], XA_LOG2E, -mn2));
                 p[4 + j] = __builtin_amdgcn_exp2f(fmaf(s1[j], XA_LOG2E, -mn2));
             }
-            l_run[qt] = l_run[qt] * alpha + (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])));
-            m_run[qt] = mn;
-            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
+            l_run = l_run * alpha + (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])));
+            m_run = mn;
+            bf16x8 pv;
 #pragma unroll
-                for (int it = 0; it < ITW; ++it) accC[it][qt] *= alpha;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pf[qt][j] = (bf16)p[j];
+            for (int j = 0; j < 8; ++j) pv[j] = (bf16)p[j];
+            pbuf[wid * 64 + lane] = pv;
+            if (g == 0) abuf[wid * 16 + r] = alpha;
         }
+#endif
+        __syncthreads();
+#if !(XA_SKIP & 4)
         // ---- C phase: lane (g, r) receives E[key = 16hh + 4g + j][i = 16 itile + r] ------------------------------------
         {
+            bf16x8 pf[NQT];
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt) {
+                pf[qt] = pbuf[qt * 64 + lane];
+                const float alpha = abuf[qt * 16 + r];
+                if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
+#pragma unroll
+                    for (int it = 0; it < ITW; ++it) accC[it][qt] *= alpha;
+                }
+            }
             const int tq = r >> 2, tp = r & 3;
             const char* p0 = img + (4 * g + tq) * PITCH + (wid * ITW * 16 + 4 * tp) * 2;
 #pragma unroll
@@ -172,18 +193,33 @@ __global__ __launch_bounds__(512) void xattn_estream_kernel(XAttnArgs a) {
                 for (int qt = 0; qt < NQT; ++qt) accC[it][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef, pf[qt], accC[it][qt], 0, 0, 0);
             }
         }
-        __syncthreads();            // the image is rewritten at the top of the next tile
+#endif
+        __syncthreads();            // image, sbuf and pbuf are rewritten during the next tile
     };
-    for (int t = t0; t < t1; t += 2) {
+    int t = t0;
+    for (; t + 1 < t1; t += 2) {        // straight-line body: every path through the loop issues the same loads, the wait counts stay exact
         tile_body(stA, t);
-        if (t + 1 < t1) tile_body(stB, t + 1);
+        tile_body(stB, t + 1);
     }
+    if (t < t1) tile_body(stA, t);
     // ---- partial context, normalised by this split's own sum; lane holds c[q = r][i = 16 itile + 4g .. +3] -----------------
-#pragma unroll
-    for (int qt = 0; qt < NQT; ++qt) {
-        float l = l_run[qt];
+    if (wid < NQT) {
+        float l = l_run;
         l += __shfl_xor(l, 16);
         l += __shfl_xor(l, 32);
+        const int q = wid * 16 + r;
+        if (g == 0) {
+            lbuf[wid * 16 + r] = l;
+            if (q < H) {
+                float* mp = a.ml + (((int64_t)row * a.n_split + split) * H + q) * 2;
+                mp[0] = m_run; mp[1] = l;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {
+        const float l = lbuf[qt * 16 + r];
         const float inv = l > 0.f ? 1.0f / l : 0.f;
         const int q = qt * 16 + r;
         if (q < H) {
@@ -195,12 +231,32 @@ __global__ __launch_bounds__(512) void xattn_estream_kernel(XAttnArgs a) {
                 for (int j = 0; j < 4; ++j) o[j] = (bf16)(accC[it][qt][j] * inv);
                 *reinterpret_cast<bf16x4*>(cp + it * 16) = o;
             }
-            if (wid == 0 && g == 0) {
-                float* mp = a.ml + (((int64_t)row * a.n_split + split) * H + q) * 2;
-                mp[0] = m_run[qt]; mp[1] = l;
-            }
         }
     }
+}
+
+// encoder output [windows][T][D] row-major -> MFMA-fragment order [windows][nt16][D/32][64 lanes][8], zero beyond key T - 1
+__global__ __launch_bounds__(256) void xattn_pack_e_kernel(const bf16* __restrict__ E, bf16* __restrict__ Ef, int T, int D, int nt16, int64_t pieces) {
+    const int ks_all = D / 32;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < pieces; p += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(p & 63);
+        const int64_t blk = p >> 6;
+        const int ks = (int)(blk % ks_all);
+        const int64_t wk = blk / ks_all;
+        const int kt = (int)(wk % nt16);
+        const int64_t win = wk / nt16;
+        const int key = kt * 16 + (lane & 15);
+        bf16x8 v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (key < T) v = *reinterpret_cast<const bf16x8*>(E + (win * T + key) * D + ks * 32 + (lane >> 4) * 8);
+        *reinterpret_cast<bf16x8*>(Ef + p * 8) = v;
+    }
+}
+int launch_xattn_pack_e(const void* E, void* Ef, int windows, int T, int D, int nt16, hipStream_t st) {
+    if (!E || !Ef || windows <= 0 || T <= 0 || D % 32 || nt16 * 16 < T || (nt16 & 1)) return -1;
+    const int64_t pieces = (int64_t)windows * nt16 * (D / 32) * 64;
+    int64_t blocks = (pieces + 255) / 256; if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(xattn_pack_e_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16*)E, (bf16*)Ef, T, D, nt16, pieces);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -384,7 +440,7 @@ int launch_xattn_qtilde(const XQTildeArgs& a, hipStream_t st) {
 
 int launch_xattn_estream(const XAttnArgs& a, hipStream_t st) {
     if (a.rows <= 0 || a.group < 1 || a.n_split < 1 || a.n_split > 8 || a.T <= 0 || !a.qt || !a.E || !a.cpart || !a.ml || a.H * 64 != a.d) return -1;
-    if ((a.T + XA_KT - 1) / XA_KT < a.n_split) return -1;
+    if (a.nt16 * 16 < a.T || (a.nt16 & 1) || a.nt16 / 2 < a.n_split) return -1;
     const dim3 grid(a.rows * a.n_split), block(512);
     switch (a.d) {
         case 384: hipLaunchKernelGGL((xattn_estream_kernel<384, 1>), grid, block, 0, st, a); break;
