@@ -30,10 +30,13 @@ constexpr float XA_LOG2E = 1.4426950408889634f;
 #ifndef XA_SKIP
 #define XA_SKIP 0                                   // diagnostics (tools/mb_xattn.sh), bit mask of the parts left out of the E-stream kernel: 1 = S product,
 #endif                                              // 2 = global loads inside the loop, 4 = C phase, 8 = softmax, 16 = image write
+#ifndef XA_CPD
+#define XA_CPD 2
+#endif
 constexpr int XA_KT = 32;                          // keys per tile (one MFMA k-step of the P·E product)
 
 // ---------------------------------------------------------------------------------------------------------
-// E-stream attention.  8 waves, tiles of 32 keys, three barriers per tile.
+// E-stream attention.  8 waves, tiles of 32 keys, two barriers per tile.
 //   E arrives in MFMA-FRAGMENT ORDER (xattn_pack_e_kernel: [window][16-key tile][k-step][lane][8]: lane (g, r) of block
 //   (kt, ks) holds E[16 kt + r][32 ks + 8g .. +8], zero beyond the last key), so a wave's 16-B-per-lane load is 1 KiB
 //   contiguous AND already the A operand of the S product:
@@ -44,7 +47,8 @@ constexpr int XA_KT = 32;                          // keys per tile (one MFMA k-
 //             lane, 8 keys per lane) and publishes P (bf16, already in B-operand order) and the rescale factor.
 //   C phase   wave w owns the 16-wide column tiles [w D/128, (w+1) D/128) of c: C^T[i][q] += E[key][i]^T . P^T, A operand =
 //             E^T via ds_read_b64_tr_b16 from the image (pitch 2D + 32 bytes: conflict-free), B operand = P from LDS.
-//   Two register sets: the loads of tile t + 2 are issued as soon as tile t's fragments are consumed.
+//   Two register sets: the loads of tile t + 2 are issued as soon as tile t's fragments are in the image; the S product of
+//   tile t + 1 shares a phase with the C phase of tile t, the softmax of tile t + 1 with the image write of tile t + 1.
 // ---------------------------------------------------------------------------------------------------------
 template <int D, int NQT>
 __global__ __launch_bounds__(512) void xattn_estream_kernel(XAttnArgs a) {
@@ -106,16 +110,10 @@ __global__ __launch_bounds__(512) void xattn_estream_kernel(XAttnArgs a) {
     __builtin_amdgcn_sched_barrier(0);                         // issue order = consumption order, or the first wait in the loop has to be vmcnt(0)
     load_tile(stB, t0 + 1);
     __builtin_amdgcn_sched_barrier(0);
-    auto tile_body = [&](bf16x8 (&st)[2][KSW], int t) {
-        if (s_role) {
-            // fragments -> image (for the transposed reads of the C phase) and, from the same registers, the S product
-#if !(XA_SKIP & 16)
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-                for (int ks = 0; ks < KSW; ++ks) *reinterpret_cast<bf16x8*>(sdst + hh * 16 * PITCH + ks * 64) = st[hh][ks];
-#endif
+    // S product of one tile, from the registers its loads landed in, to the partial-score buffer
+    auto s_phase = [&](bf16x8 (&st)[2][KSW]) {
 #if !(XA_SKIP & 1)
+        if (s_role) {
 #pragma unroll
             for (int qt = 0; qt < NQT; ++qt)
 #pragma unroll
@@ -125,15 +123,25 @@ __global__ __launch_bounds__(512) void xattn_estream_kernel(XAttnArgs a) {
                     for (int ks = 0; ks < KSW; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st[hh][ks], qf[qt][ks], acc, 0, 0, 0);
                     sbuf[((wid * NQT + qt) * 2 + hh) * 64 + lane] = acc;
                 }
-#endif
         }
-        __syncthreads();
+#endif
+    };
+    // phase A of tile t: its fragments -> the image (then its registers take the loads of tile t + 2), while wave qt < NQT runs
+    // the online softmax of query tile qt on the partial scores the previous phase B left
+    auto phase_a = [&](bf16x8 (&st)[2][KSW], int t) {
+#if !(XA_SKIP & 16)
+        if (s_role) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int ks = 0; ks < KSW; ++ks) *reinterpret_cast<bf16x8*>(sdst + hh * 16 * PITCH + ks * 64) = st[hh][ks];
+        }
+#endif
 #if !(XA_SKIP & 2)
         load_tile(st, t + 2);
 #endif
-        // ---- online softmax of query tile wid: lane (g, r) holds keys 4g..4g+3 of both 16-key halves for query r ------------
 #if !(XA_SKIP & 8)
-        if (wid < NQT) {
+        if (wid < NQT) {              // lane (g, r) holds keys 4g..4g+3 of both 16-key halves for query r
             f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
 #pragma unroll
             for (int w = 0; w < NSW; ++w) {                     // fixed order: the K slices in ascending order
@@ -168,40 +176,67 @@ __global__ __launch_bounds__(512) void xattn_estream_kernel(XAttnArgs a) {
             if (g == 0) abuf[wid * 16 + r] = alpha;
         }
 #endif
-        __syncthreads();
+    };
+    // C phase of the tile in the image: lane (g, r) receives E[key = 16hh + 4g + j][i = 16 itile + r]
+    auto c_phase = [&]() {
 #if !(XA_SKIP & 4)
-        // ---- C phase: lane (g, r) receives E[key = 16hh + 4g + j][i = 16 itile + r] ------------------------------------
-        {
-            bf16x8 pf[NQT];
+        bf16x8 pf[NQT];
 #pragma unroll
-            for (int qt = 0; qt < NQT; ++qt) {
-                pf[qt] = pbuf[qt * 64 + lane];
-                const float alpha = abuf[qt * 16 + r];
-                if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
+        for (int qt = 0; qt < NQT; ++qt) {
+            pf[qt] = pbuf[qt * 64 + lane];
+            const float alpha = abuf[qt * 16 + r];
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
 #pragma unroll
-                    for (int it = 0; it < ITW; ++it) accC[it][qt] *= alpha;
-                }
-            }
-            const int tq = r >> 2, tp = r & 3;
-            const char* p0 = img + (4 * g + tq) * PITCH + (wid * ITW * 16 + 4 * tp) * 2;
-#pragma unroll
-            for (int it = 0; it < ITW; ++it) {
-                const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(p0 + it * 32));
-                const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(p0 + it * 32 + 16 * PITCH));
-                const bf16x8 ef = __builtin_bit_cast(bf16x8, (i16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-#pragma unroll
-                for (int qt = 0; qt < NQT; ++qt) accC[it][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef, pf[qt], accC[it][qt], 0, 0, 0);
+                for (int it = 0; it < ITW; ++it) accC[it][qt] *= alpha;
             }
         }
+        const int tq = r >> 2, tp = r & 3;
+        const char* p0 = img + (4 * g + tq) * PITCH + (wid * ITW * 16 + 4 * tp) * 2;
+        // the transposed reads run XA_CPD column tiles ahead of the MFMAs that consume them (one LDS latency per tile otherwise)
+        constexpr int CPD = ITW < XA_CPD ? ITW : XA_CPD;
+        i16x4 lo[ITW], hi[ITW];
+#pragma unroll
+        for (int it = 0; it < CPD; ++it) {
+            lo[it] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(p0 + it * 32));
+            hi[it] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(p0 + it * 32 + 16 * PITCH));
+        }
+#pragma unroll
+        for (int it = 0; it < ITW; ++it) {
+            if (it + CPD < ITW) {
+                lo[it + CPD] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(p0 + (it + CPD) * 32));
+                hi[it + CPD] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(p0 + (it + CPD) * 32 + 16 * PITCH));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 ef = __builtin_bit_cast(bf16x8, (i16x8)__builtin_shufflevector(lo[it], hi[it], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt) accC[it][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef, pf[qt], accC[it][qt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #endif
-        __syncthreads();            // image, sbuf and pbuf are rewritten during the next tile
     };
+    // Two barriers per tile.  Phase A(t): image write of tile t || softmax of tile t (scores from phase B(t - 1)).
+    // Phase B(t): C phase of tile t (image + P), then the S product of tile t + 1 from the other register set (its loads have had
+    // a whole tile to land).  Past the last tile the loads return zeros and the S product is idle work that nobody reads.
+    s_phase(stA);
+    __syncthreads();
     int t = t0;
     for (; t + 1 < t1; t += 2) {        // straight-line body: every path through the loop issues the same loads, the wait counts stay exact
-        tile_body(stA, t);
-        tile_body(stB, t + 1);
+        phase_a(stA, t);
+        __syncthreads();
+        c_phase();
+        s_phase(stB);
+        __syncthreads();
+        phase_a(stB, t + 1);
+        __syncthreads();
+        c_phase();
+        s_phase(stA);
+        __syncthreads();
     }
-    if (t < t1) tile_body(stA, t);
+    if (t < t1) {
+        phase_a(stA, t);
+        __syncthreads();
+        c_phase();
+    }
     // ---- partial context, normalised by this split's own sum; lane holds c[q = r][i = 16 itile + 4g .. +3] -----------------
     if (wid < NQT) {
         float l = l_run;
