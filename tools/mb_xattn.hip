@@ -27,7 +27,7 @@ int main(int argc, char** argv) {
     const int rows = argc > 1 ? atoi(argv[1]) : 64;
     const int d = argc > 2 ? atoi(argv[2]) : 1280;
     const int S = argc > 3 ? atoi(argv[3]) : 4;
-    const int H = d / 64, T = 1500, L = 32, NSQ = 10;
+    const int H = d / 64, T = 1500, L = 32, NSQ = argc > 4 ? atoi(argv[4]) : 4;
     const float scale = powf(64.f, -0.25f);
     hipStream_t st; CK(hipStreamCreate(&st));
     const size_t e_elems = (size_t)rows * T * d;
@@ -49,9 +49,22 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&qt, (size_t)rows * H * d * 2)); CK(hipMalloc(&cpart, (size_t)rows * S * H * d * 2)); CK(hipMalloc(&ml, (size_t)rows * S * H * 2 * 4));
     CK(hipMalloc(&att, (size_t)rows * d * 2));
     CK(hipStreamSynchronize(st));
-    XQTildeArgs qa; qa.q_partial = qpart; qa.q_bias = qbias; qa.q_nsplit = NSQ; qa.WkT = WkT; qa.qt = qt; qa.scale = scale; qa.rows = rows; qa.H = H; qa.d = d;
+    // the kernels read the two weights in MFMA-fragment order (same packing as wx_finalize's)
+    bf16 *Wk_pk, *Wv_pk; CK(hipMalloc(&Wk_pk, (size_t)d * d * 2)); CK(hipMalloc(&Wv_pk, (size_t)d * d * 2));
+    {
+        std::vector<uint16_t> w0((size_t)d * d), w1((size_t)d * d), k2((size_t)d * d), v2((size_t)d * d);
+        CK(hipMemcpy(w0.data(), WkT, w0.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(w1.data(), Wv, w1.size() * 2, hipMemcpyDeviceToHost));
+        size_t at = 0;
+        for (int h = 0; h < H; ++h) for (int it = 0; it < d / 16; ++it) for (int ks = 0; ks < 2; ++ks) for (int lane = 0; lane < 64; ++lane) for (int j = 0; j < 8; ++j)
+            k2[at++] = w0[(size_t)(it * 16 + (lane & 15)) * d + h * 64 + ks * 32 + (lane >> 4) * 8 + j];      // WkT[i][c] = Wk[c][i]
+        at = 0;
+        for (int u = 0; u < d / 16; ++u) for (int kb = 0; kb < d / 32; ++kb) for (int lane = 0; lane < 64; ++lane) for (int j = 0; j < 8; ++j)
+            v2[at++] = w1[(size_t)(u * 16 + (lane & 15)) * d + kb * 32 + (lane >> 4) * 8 + j];
+        CK(hipMemcpy(Wk_pk, k2.data(), k2.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(Wv_pk, v2.data(), v2.size() * 2, hipMemcpyHostToDevice));
+    }
+    XQTildeArgs qa; qa.q_partial = qpart; qa.q_bias = qbias; qa.q_nsplit = NSQ; qa.Wk_pk = Wk_pk; qa.qt = qt; qa.scale = scale; qa.rows = rows; qa.H = H; qa.d = d;
     XAttnArgs xa; xa.nt16 = nt16; xa.qt = qt; xa.E = Ef[0]; xa.cpart = cpart; xa.ml = ml; xa.rows = rows; xa.H = H; xa.d = d; xa.T = T; xa.group = 1; xa.n_split = S;
-    XCProjArgs ca; ca.cpart = cpart; ca.ml = ml; ca.n_split = S; ca.Wv = Wv; ca.bv = bv; ca.out = att; ca.ldo = d; ca.rows = rows; ca.H = H; ca.d = d;
+    XCProjArgs ca; ca.cpart = cpart; ca.ml = ml; ca.n_split = S; ca.Wv_pk = Wv_pk; ca.bv = bv; ca.out = att; ca.ldo = d; ca.rows = rows; ca.H = H; ca.d = d;
     if (launch_xattn_qtilde(qa, st) || launch_xattn_estream(xa, st) || launch_xattn_cproj(ca, st)) { printf("launch failed\n"); return 1; }
     CK(hipStreamSynchronize(st));
     // ---- host reference for a few rows --------------------------------------------------------------------------

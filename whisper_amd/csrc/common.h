@@ -161,7 +161,7 @@ int launch_attn_flash_bf16(const AttnArgs& a, hipStream_t st); // MFMA flash att
 // ---- decoder cross-attention on the encoder output (xattn.hip) ---------------------------------------------
 struct XQTildeArgs {                     // q~[row][h][:] = s * Wk_h^T bf16((bias + sum of split-K tiles) * s)
     const float* q_partial = nullptr; const float* q_bias = nullptr; int q_nsplit = 0;   // [split][rows][d] tiles of the query projection
-    const bf16* WkT = nullptr;           // [d][d]: cross-attention key weight TRANSPOSED (row i, column h*64 + c)
+    const bf16* Wk_pk = nullptr;         // cross-attention key weight, per head in MFMA-fragment order [H][d / 16][2][64][8] (xattn.hip)
     bf16* qt = nullptr;                  // [rows][H][d]
     float scale = 1.f;                   // head_dim^-0.25
     int rows = 0, H = 0, d = 0;
@@ -177,7 +177,7 @@ struct XAttnArgs {                       // one workgroup per (row, key split)
 };
 struct XCProjArgs {                      // out[row][h*64 + c] = bv + Wv_h . bf16(sum_s w_s cpart_s)
     const bf16* cpart = nullptr; const float* ml = nullptr; int n_split = 1;
-    const bf16* Wv = nullptr;            // [d][d] cross-attention value weight (row h*64 + c)
+    const bf16* Wv_pk = nullptr;         // cross-attention value weight [d][d] in MFMA-fragment order [d / 16][d / 32][64][8]
     const float* bv = nullptr;           // [d]
     bf16* out = nullptr; int64_t ldo = 0;
     int rows = 0, H = 0, d = 0;

@@ -40,7 +40,8 @@ struct LayerW {
     float *lnx_g = nullptr, *lnx_b = nullptr;      // cross-attention LN (decoder only)
     void* xq = nullptr; float* xbq = nullptr;      // cross query
     void* xkv = nullptr; float* xbkv = nullptr;    // fused cross key|value
-    void* xk_t = nullptr;                          // bf16 engines: cross key weight TRANSPOSED [d in][d out] (xattn.hip)
+    void* xk_pk = nullptr;                         // bf16 engines: cross key weight, transposed, per head in MFMA-fragment order (xattn.hip)
+    void* xv_pk = nullptr;                         // bf16 engines: cross value weight in MFMA-fragment order (xattn.hip)
     void* xo = nullptr; float* xbo = nullptr;
     float *ln2_g = nullptr, *ln2_b = nullptr;
     void* w1 = nullptr; float* b1 = nullptr; void* w2 = nullptr; float* b2 = nullptr;
@@ -414,10 +415,24 @@ int wx_finalize(wx_engine* e) {
             if ((r = upload_f32(e, qb->data.data(), d, &L.xbq))) return r;
             if ((r = upload_w(e, kv.data(), kv.size(), &L.xkv))) return r;
             if (e->xattn) {
-                std::vector<float> kt((size_t)d * d);
-                for (int o = 0; o < d; ++o)
-                    for (int in = 0; in < d; ++in) kt[(size_t)in * d + o] = k->data[(size_t)o * d + in];
-                if ((r = upload_w(e, kt.data(), kt.size(), &L.xk_t))) return r;
+                // fragment order of v_mfma_f32_16x16x32_bf16's A operand: lane (g, r) of a block holds row r, k = 8g .. 8g + 7
+                //   key:   [head][d / 16 tiles of E's feature index i][2 k-steps over the head's 64 outputs c]: Wk[64 h + 32 ks + 8 g + j][16 it + r]
+                //   value: [d / 16 tiles of the output index n][d / 32 k-steps over E's feature index]:        Wv[16 u + r][32 kb + 8 g + j]
+                std::vector<float> kp((size_t)d * d), vp((size_t)d * d);
+                size_t at = 0;
+                for (int h = 0; h < d / 64; ++h)
+                    for (int it = 0; it < d / 16; ++it)
+                        for (int ks = 0; ks < 2; ++ks)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int j = 0; j < 8; ++j)
+                                    kp[at++] = k->data[(size_t)(h * 64 + ks * 32 + (lane >> 4) * 8 + j) * d + it * 16 + (lane & 15)];
+                at = 0;
+                for (int u = 0; u < d / 16; ++u)
+                    for (int kb = 0; kb < d / 32; ++kb)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j)
+                                vp[at++] = v->data[(size_t)(u * 16 + (lane & 15)) * d + kb * 32 + (lane >> 4) * 8 + j];
+                if ((r = upload_w(e, kp.data(), kp.size(), &L.xk_pk)) || (r = upload_w(e, vp.data(), vp.size(), &L.xv_pk))) return r;
             }
             if ((r = upload_f32(e, kvb.data(), kvb.size(), &L.xbkv))) return r;
             if ((r = upload_w(e, o->data.data(), o->data.size(), &L.xo))) return r;
@@ -903,7 +918,7 @@ static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, floa
             // cross-attention on the encoder output itself (xattn.hip): q~ = s Wk_h^T q_h, one stream over E per row for
             // all heads, then the value projection of the context vectors.  Row r attends window (b0 + r) / G.
             XQTildeArgs qa;
-            qa.q_partial = gpartial; qa.q_bias = L.xbq; qa.q_nsplit = s_dd; qa.WkT = (const bf16*)L.xk_t; qa.qt = (bf16*)e->x_qt;
+            qa.q_partial = gpartial; qa.q_bias = L.xbq; qa.q_nsplit = s_dd; qa.Wk_pk = (const bf16*)L.xk_pk; qa.qt = (bf16*)e->x_qt;
             qa.scale = e->qk_scale; qa.rows = B; qa.H = e->Ht; qa.d = d;
             WX_TRY(launch_xattn_qtilde(qa, st));
             XAttnArgs xa;
@@ -914,7 +929,7 @@ static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, floa
             if (prof) { HIP_TRY(hipEventRecord(e->prof_events[e->prof_used + 1], st)); e->prof_used += 2; }
             XCProjArgs ca;
             ca.cpart = (const bf16*)e->x_cpart; ca.ml = e->x_ml; ca.n_split = e->x_split;
-            ca.Wv = (const bf16*)L.xkv + (size_t)d * d; ca.bv = L.xbkv + d; ca.out = (bf16*)datt; ca.ldo = d; ca.rows = B; ca.H = e->Ht; ca.d = d;
+            ca.Wv_pk = (const bf16*)L.xv_pk; ca.bv = L.xbkv + d; ca.out = (bf16*)datt; ca.ldo = d; ca.rows = B; ca.H = e->Ht; ca.d = d;
             WX_TRY(launch_xattn_cproj(ca, st));
         } else {
             AttnArgs a;

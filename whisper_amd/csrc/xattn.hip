@@ -295,26 +295,27 @@ int launch_xattn_pack_e(const void* E, void* Ef, int windows, int T, int D, int 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// q̃: one workgroup (4 waves) per (head, 256 output columns).  The head's 64 query columns of every row are assembled from
-// the query projection's split-K tiles (+ bias, x s, bf16: the rounding point of a stored query) into LDS; each wave then
-// runs 4 column units x MT row tiles x 2 k-steps.  Weights: WkT [d][d] = the cross-attention key weight transposed, so that
-// the 64 inputs of a head are contiguous in a row.
+// q̃: one workgroup (4 waves) per (head, 256 output columns, 32 rows).  The head's 64 query columns of the rows are assembled
+// from the query projection's split-K tiles (+ bias, x s, bf16: the rounding point of a stored query) into LDS; each wave then
+// runs 4 column units x MT row tiles x 2 k-steps.  Weights: Wk_pk = the cross-attention key weight, transposed and cut per head
+// into MFMA-fragment order [head][d / 16 column tiles][2 k-steps][64 lanes][8] (lane (g, r) of block (h, it, ks) holds
+// Wk[64 h + 32 ks + 8 g .. +8][16 it + r]): every wave load is 1 KiB contiguous.
 // ---------------------------------------------------------------------------------------------------------
 template <int MT, int MS>                                     // MS: split-K tiles fetched per element (>= q_nsplit)
 __global__ __launch_bounds__(256) void xattn_qtilde_kernel(XQTildeArgs a) {
     constexpr int ROWB = 64 * 2 + 32;                         // LDS row: 64 bf16 + pad
     __shared__ __attribute__((aligned(16))) char xs[MT * 16 * ROWB];
-    const int h = blockIdx.x, n0 = blockIdx.y * 256;
+    const int h = blockIdx.x, n0 = blockIdx.y * 256, m0 = blockIdx.z * 32;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, r = lane & 15;
-    const int d = a.d, M = a.rows;
+    const int d = a.d, M = a.rows, n_it = d / 16;
     // weights first: they depend on nothing
     bf16x8 w[4][2];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        int i = n0 + (wid * 4 + u) * 16 + r; if (i > d - 1) i = d - 1;
+        int it = n0 / 16 + wid * 4 + u; if (it > n_it - 1) it = n_it - 1;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) w[u][ks] = *reinterpret_cast<const bf16x8*>(a.WkT + (int64_t)i * d + h * 64 + ks * 32 + g * 8);
+        for (int ks = 0; ks < 2; ++ks) w[u][ks] = *reinterpret_cast<const bf16x8*>(a.Wk_pk + (((int64_t)h * n_it + it) * 2 + ks) * 512 + lane * 8);
     }
     // the head's query slice: MT*16 rows x 64 columns, 4 columns (one f32x4 per partial tile) per item
     // (all tiles of an element in flight at once: a runtime-bounded loop of loads is a chain of round trips; tiles past
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(256) void xattn_qtilde_kernel(XQTildeArgs a) {
     for (int it0 = 0; it0 < MT * 16 * 16; it0 += 256) {
         const int it = it0 + tid;
         const int row = it >> 4, c4 = (it & 15) * 4;
-        const int rr = row < M ? row : M - 1;
+        const int rr = m0 + row < M ? m0 + row : M - 1;
         f32x4 pt[MS];
 #pragma unroll
         for (int s = 0; s < MS; ++s)
@@ -352,14 +353,14 @@ __global__ __launch_bounds__(256) void xattn_qtilde_kernel(XQTildeArgs a) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) acc[u][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[u][ks], xf[i], acc[u][i], 0, 0, 0);
     }
-    // lane holds q̃[row = 16 i + r][col = n0 + 16 (4 wid + u) + 4g .. +3]
+    // lane holds q̃[row = m0 + 16 i + r][col = n0 + 16 (4 wid + u) + 4g .. +3]
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int col = n0 + (wid * 4 + u) * 16 + 4 * g;
         if (col >= d) continue;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            const int row = i * 16 + r;
+            const int row = m0 + i * 16 + r;
             if (row >= M) continue;
             bf16x4 o;
 #pragma unroll
@@ -370,26 +371,27 @@ __global__ __launch_bounds__(256) void xattn_qtilde_kernel(XQTildeArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Output side: one workgroup (8 waves) per (head, 16 rows).  The rows' context vectors are combined from the key splits
-// (w_s = l_s e^(m_s - M) / Σ, fp32) and rounded to bf16 into LDS; waves = 4 column units x 2 K halves; the halves meet in LDS.
+// Output side: one workgroup (4 waves) per (head, 8 rows, 32 of the head's 64 output columns).  The rows' context vectors are
+// combined from the key splits (w_s = l_s e^(m_s - M) / Σ, fp32) and rounded to bf16 into LDS; waves = 2 column units x 2 K
+// halves; the halves meet in LDS.  Wv_pk: the value weight [d][d] in MFMA-fragment order [d / 16][d / 32][64 lanes][8].
 // ---------------------------------------------------------------------------------------------------------
 template <int D, int MS>                                      // MS: key splits fetched per chunk (>= n_split)
-__global__ __launch_bounds__(512) void xattn_cproj_kernel(XCProjArgs a) {
+__global__ __launch_bounds__(256) void xattn_cproj_kernel(XCProjArgs a) {
     constexpr int PITCH = D * 2 + 32, KH = D / 2, KSTEPS = KH / 32;
     constexpr int CR = D / 8, CPT = (CR + 31) / 32;           // 16-B chunks per row; per thread (32 threads per row)
-    __shared__ __attribute__((aligned(16))) char cs[16 * PITCH];
-    __shared__ __attribute__((aligned(16))) f32x4 red[4 * 64];
-    const int h = blockIdx.x, m0 = blockIdx.y * 16;
+    __shared__ __attribute__((aligned(16))) char cs[8 * PITCH];
+    __shared__ __attribute__((aligned(16))) f32x4 red[2 * 64];
+    const int h = blockIdx.x, m0 = blockIdx.y * 8, half = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, r = lane & 15;
-    const int unit = wid & 3, kh = wid >> 2;
+    const int unit = wid & 1, kh = wid >> 1;
     const int M = a.rows, H = a.H, S = a.n_split;
     // every load that depends on nothing is issued before the first wait: weights, split statistics, split contexts
     bf16x8 w[KSTEPS];
     {
-        const bf16* wp = a.Wv + (int64_t)(h * 64 + unit * 16 + r) * D + kh * KH + g * 8;
+        const bf16* wp = a.Wv_pk + (((int64_t)(h * 4 + half * 2 + unit) * (D / 32)) + kh * KSTEPS) * 512 + lane * 8;
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) w[ks] = *reinterpret_cast<const bf16x8*>(wp + ks * 32);
+        for (int ks = 0; ks < KSTEPS; ++ks) w[ks] = *reinterpret_cast<const bf16x8*>(wp + ks * 512);
     }
     const int lr = tid >> 5, c0 = tid & 31;
     const int row = m0 + lr < M ? m0 + lr : M - 1;
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(512) void xattn_cproj_kernel(XCProjArgs a) {
     }
     __syncthreads();
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    const char* xp = cs + r * PITCH + (kh * KH + g * 8) * 2;
+    const char* xp = cs + (r & 7) * PITCH + (kh * KH + g * 8) * 2;          // B operand columns 8..15 repeat rows 0..7 and are dropped
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
         const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xp + ks * 64);
@@ -443,8 +445,8 @@ __global__ __launch_bounds__(512) void xattn_cproj_kernel(XCProjArgs a) {
     __syncthreads();
     if (kh == 0) {
         const f32x4 o2 = red[unit * 64 + lane];
-        const int orow = m0 + r, col = h * 64 + unit * 16 + 4 * g;       // lane holds att[row][col .. col+3]
-        if (orow < M) {
+        const int orow = m0 + r, col = h * 64 + half * 32 + unit * 16 + 4 * g;       // lane holds att[row][col .. col+3]
+        if (r < 8 && orow < M) {
             const f32x4 b = *reinterpret_cast<const f32x4*>(a.bv + col);
             bf16x4 o;
 #pragma unroll
@@ -456,17 +458,12 @@ __global__ __launch_bounds__(512) void xattn_cproj_kernel(XCProjArgs a) {
 
 template <int MS>
 static void launch_qtilde_mt(const XQTildeArgs& a, dim3 grid, hipStream_t st) {
-    switch ((a.rows + 15) / 16) {
-        case 1: hipLaunchKernelGGL((xattn_qtilde_kernel<1, MS>), grid, dim3(256), 0, st, a); break;
-        case 2: hipLaunchKernelGGL((xattn_qtilde_kernel<2, MS>), grid, dim3(256), 0, st, a); break;
-        case 3: hipLaunchKernelGGL((xattn_qtilde_kernel<3, MS>), grid, dim3(256), 0, st, a); break;
-        case 4: hipLaunchKernelGGL((xattn_qtilde_kernel<4, MS>), grid, dim3(256), 0, st, a); break;
-        default: hipLaunchKernelGGL((xattn_qtilde_kernel<5, MS>), grid, dim3(256), 0, st, a); break;
-    }
+    if (a.rows <= 16) hipLaunchKernelGGL((xattn_qtilde_kernel<1, MS>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((xattn_qtilde_kernel<2, MS>), grid, dim3(256), 0, st, a);
 }
 int launch_xattn_qtilde(const XQTildeArgs& a, hipStream_t st) {
-    if (a.rows <= 0 || a.rows > DG_MAX_ROWS || a.d % 128 || a.H * 64 != a.d || !a.q_partial || !a.q_bias || !a.WkT || !a.qt || a.q_nsplit < 1 || a.q_nsplit > 16) return -1;
-    const dim3 grid(a.H, (a.d + 255) / 256);
+    if (a.rows <= 0 || a.rows > DG_MAX_ROWS || a.d % 128 || a.H * 64 != a.d || !a.q_partial || !a.q_bias || !a.Wk_pk || !a.qt || a.q_nsplit < 1 || a.q_nsplit > 16) return -1;
+    const dim3 grid(a.H, (a.d + 255) / 256, (a.rows + 31) / 32);
     if (a.q_nsplit <= 4) launch_qtilde_mt<4>(a, grid, st);
     else if (a.q_nsplit <= 10) launch_qtilde_mt<10>(a, grid, st);
     else launch_qtilde_mt<16>(a, grid, st);
@@ -493,19 +490,19 @@ int launch_xattn_estream(const XAttnArgs& a, hipStream_t st) {
 template <int MS>
 static bool launch_cproj_d(const XCProjArgs& a, dim3 grid, hipStream_t st) {
     switch (a.d) {
-        case 128: hipLaunchKernelGGL((xattn_cproj_kernel<128, MS>), grid, dim3(512), 0, st, a); return true;
-        case 256: hipLaunchKernelGGL((xattn_cproj_kernel<256, MS>), grid, dim3(512), 0, st, a); return true;
-        case 384: hipLaunchKernelGGL((xattn_cproj_kernel<384, MS>), grid, dim3(512), 0, st, a); return true;
-        case 512: hipLaunchKernelGGL((xattn_cproj_kernel<512, MS>), grid, dim3(512), 0, st, a); return true;
-        case 768: hipLaunchKernelGGL((xattn_cproj_kernel<768, MS>), grid, dim3(512), 0, st, a); return true;
-        case 1024: hipLaunchKernelGGL((xattn_cproj_kernel<1024, MS>), grid, dim3(512), 0, st, a); return true;
-        case 1280: hipLaunchKernelGGL((xattn_cproj_kernel<1280, MS>), grid, dim3(512), 0, st, a); return true;
+        case 128: hipLaunchKernelGGL((xattn_cproj_kernel<128, MS>), grid, dim3(256), 0, st, a); return true;
+        case 256: hipLaunchKernelGGL((xattn_cproj_kernel<256, MS>), grid, dim3(256), 0, st, a); return true;
+        case 384: hipLaunchKernelGGL((xattn_cproj_kernel<384, MS>), grid, dim3(256), 0, st, a); return true;
+        case 512: hipLaunchKernelGGL((xattn_cproj_kernel<512, MS>), grid, dim3(256), 0, st, a); return true;
+        case 768: hipLaunchKernelGGL((xattn_cproj_kernel<768, MS>), grid, dim3(256), 0, st, a); return true;
+        case 1024: hipLaunchKernelGGL((xattn_cproj_kernel<1024, MS>), grid, dim3(256), 0, st, a); return true;
+        case 1280: hipLaunchKernelGGL((xattn_cproj_kernel<1280, MS>), grid, dim3(256), 0, st, a); return true;
         default: return false;
     }
 }
 int launch_xattn_cproj(const XCProjArgs& a, hipStream_t st) {
-    if (a.rows <= 0 || a.n_split < 1 || a.n_split > 8 || !a.cpart || !a.ml || !a.Wv || !a.bv || !a.out || a.H * 64 != a.d || a.ldo % 4) return -1;
-    const dim3 grid(a.H, (a.rows + 15) / 16);
+    if (a.rows <= 0 || a.n_split < 1 || a.n_split > 8 || !a.cpart || !a.ml || !a.Wv_pk || !a.bv || !a.out || a.H * 64 != a.d || a.ldo % 4) return -1;
+    const dim3 grid(a.H, (a.rows + 7) / 8, 2);
     const bool ok = a.n_split <= 4 ? launch_cproj_d<4>(a, grid, st) : launch_cproj_d<8>(a, grid, st);
     if (!ok) return -1;
     return hipGetLastError() == hipSuccess ? 0 : -2;
