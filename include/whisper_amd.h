@@ -182,6 +182,11 @@ int wx_get_profile(wx_engine* e, double* total_ms, int64_t* launches);
  * (about half as much again). */
 int64_t wx_weight_bytes(wx_engine* e);
 int64_t wx_workspace_bytes(wx_engine* e);
+/* which form of the decoder cross-attention this engine's greedy / sampling decode runs: 0 = on cached per-layer K/V (upstream's
+ * form: openai-whisper MultiHeadAttention.forward with kv_cache), 1 = on the encoder output itself with the key / value
+ * projections moved to the query side (bf16 engines with max_batch >= 32; same attention, different bf16 rounding points:
+ * DESIGN.md section 4).  Fixed at wx_create; the parity tests pick the matching oracle form with it. */
+int32_t wx_cross_attention_form(wx_engine* e);
 
 #ifdef __cplusplus
 }

@@ -225,9 +225,14 @@ class OracleWhisper:
     independent evaluation of the same rounded model (same rounding points, float64 accumulation): the distance between
     the two emulations MEASURES that noise floor, and the GPU tests bound the device's distance by a small multiple of it."""
 
-    def __init__(self, dims, sd: Dict[str, torch.Tensor], emulate_bf16: bool = False, acc_dtype: torch.dtype = torch.float32):
+    def __init__(self, dims, sd: Dict[str, torch.Tensor], emulate_bf16: bool = False, acc_dtype: torch.dtype = torch.float32,
+                 cross_form: str = "encoder_output"):
+        """``cross_form`` (bf16 emulation only): "encoder_output" = the engine's cross-attention on E itself (bf16 engines with
+        max_batch >= 32), "kv" = on cached K/V (smaller engines, beam search); WhisperEngine.cross_form says which one runs."""
+        assert cross_form in ("encoder_output", "kv")
         self.dims = dims
         self.bf16 = bool(emulate_bf16)
+        self.absorbed = self.bf16 and cross_form == "encoder_output"
         self.dt = acc_dtype
         self.sd = {k: v.to(acc_dtype) for k, v in sd.items()}
         if self.bf16:
@@ -306,7 +311,7 @@ class OracleWhisper:
     def cross_kv(self, xa: torch.Tensor):
         """Per decoder layer (K, V) of the encoder output, computed once per window
         (hf:...modeling_whisper.py:311-335 cross-KV reuse)."""
-        if self.bf16:           # the bf16 engine attends the encoder output itself: nothing to project
+        if self.absorbed:       # the engine attends the encoder output itself: nothing to project
             return [xa] * self.dims.n_text_layer
         out = []
         for i in range(self.dims.n_text_layer):
@@ -336,7 +341,7 @@ class OracleWhisper:
                                     dims.n_text_head, mask)
             x = x + self._lin(a, p + ".attn.out")
             h = self._ln(x, p + ".cross_attn_ln")
-            if self.bf16:
+            if self.absorbed:
                 a = self._cross_attention_absorbed(h, cross[i], p + ".cross_attn", dims.n_text_head)
             else:
                 ck, cv = cross[i]

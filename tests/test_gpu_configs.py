@@ -51,7 +51,8 @@ def check_windows_against_emulation(eng, dims, sd, mel, n_windows, probe, n_step
     """Encoder output, teacher-forced logits and margin-gated greedy ids of the windows in `probe`, decoded inside the full
     batch, against the bf16-emulating oracle run on those windows alone."""
     tok = eng.tok
-    om = wo.OracleWhisper(dims, sd, emulate_bf16=True)
+    assert eng.cross_form == "encoder_output"            # 32 rows and up: cross-attention on the encoder output
+    om = wo.OracleWhisper(dims, sd, emulate_bf16=True, cross_form=eng.cross_form)
     mw = torch.stack([mel[:, w * 3000:(w + 1) * 3000].cpu() for w in probe])
     init = eng.initial_tokens(0)
     toks = torch.tensor([init + [100, 2000, 31337]] * len(probe))
@@ -59,7 +60,7 @@ def check_windows_against_emulation(eng, dims, sd, mel, n_windows, probe, n_step
         xa = om.encode(mw)
         ref_lg = om.logits(toks, xa)
         ref = wo.greedy_decode(om, xa, init, tok, eng.suppress_ids, max_new_tokens=n_steps)
-        o64 = wo.OracleWhisper(dims, sd, emulate_bf16=True, acc_dtype=torch.float64)        # the noise floor: one window is enough
+        o64 = wo.OracleWhisper(dims, sd, emulate_bf16=True, acc_dtype=torch.float64, cross_form=eng.cross_form)        # the noise floor: one window is enough
         x64 = o64.encode(mw[:1])
         lg64 = o64.logits(toks[:1], x64)
         del o64

@@ -2,6 +2,8 @@
 
 Tolerances (north_star): mel within 1e-4 relative; encoder / logits within the fp32 and bf16 tolerances written
 below; greedy token ids bit-exact in fp32 mode."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -56,12 +58,21 @@ def models():
     from whisper_amd.engine import WhisperEngine
     cache = {}
 
-    def get(name, precision, max_batch=4, **kw):
-        key = (name, precision, max_batch, tuple(sorted(kw.items())))
+    def get(name, precision, max_batch=4, xattn=False, **kw):
+        """xattn=True: a bf16 engine below 32 rows that runs the decoder cross-attention on the encoder output all the same
+        (WX_XATTN=1 at wx_create), so the small models cover both forms"""
+        key = (name, precision, max_batch, xattn, tuple(sorted(kw.items())))
         if key not in cache:
             dims = ck.dims_for(name)
             sd = ck.synthetic_state_dict(dims, seed=0, **kw)
-            cache[key] = (dims, sd, WhisperEngine(dims, sd, precision=precision, max_batch=max_batch))
+            if xattn:
+                os.environ["WX_XATTN"] = "1"
+            try:
+                eng = WhisperEngine(dims, sd, precision=precision, max_batch=max_batch)
+            finally:
+                os.environ.pop("WX_XATTN", None)
+            assert eng.cross_form == ("encoder_output" if (precision == "bf16" and (xattn or max_batch >= 32)) else "kv")
+            cache[key] = (dims, sd, eng)
         return cache[key]
 
     yield get
@@ -122,13 +133,17 @@ def test_mel_two_stage_matches_sharded_max(models):
     assert torch.equal(out, whole)
 
 
-@pytest.mark.parametrize("name,precision,gain", [("micro", "fp32", 3.0), ("tiny", "fp32", 3.0), ("micro", "bf16", 1.0),
-                                                 ("tiny", "bf16", 1.0), ("tiny", "bf16", 3.0), ("micro", "bf16", 3.0)])
-def test_encoder_and_logits_parity(models, name, precision, gain):
-    dims, sd, eng = models(name, precision, attn_gain=gain)
+@pytest.mark.parametrize("name,precision,gain,xattn", [("micro", "fp32", 3.0, False), ("tiny", "fp32", 3.0, False),
+                                                       ("micro", "bf16", 1.0, False), ("tiny", "bf16", 1.0, False), ("tiny", "bf16", 3.0, False),
+                                                       ("micro", "bf16", 3.0, False), ("micro", "bf16", 1.0, True), ("tiny", "bf16", 1.0, True),
+                                                       ("tiny", "bf16", 3.0, True), ("micro", "bf16", 3.0, True)])
+def test_encoder_and_logits_parity(models, name, precision, gain, xattn):
+    """bf16: both forms of the decoder cross-attention (on cached K/V; on the encoder output), each against the emulation of
+    its own rounding points"""
+    dims, sd, eng = models(name, precision, xattn=xattn, attn_gain=gain)
     om = wo.OracleWhisper(dims, sd)
-    oe = wo.OracleWhisper(dims, sd, emulate_bf16=True) if precision == "bf16" else None
-    o64 = wo.OracleWhisper(dims, sd, emulate_bf16=True, acc_dtype=torch.float64) if precision == "bf16" else None
+    oe = wo.OracleWhisper(dims, sd, emulate_bf16=True, cross_form=eng.cross_form) if precision == "bf16" else None
+    o64 = wo.OracleWhisper(dims, sd, emulate_bf16=True, acc_dtype=torch.float64, cross_form=eng.cross_form) if precision == "bf16" else None
     mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(s), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000] for s in (0, 1)])
     with torch.no_grad():
         xa = om.encode(mels)
@@ -389,11 +404,12 @@ def test_beam_search_bf16_shares_cross_kv(models):
         assert max(c[1] / max(len(c[0]), 1) for c in b5["candidates"][b]) >= g["sum_logprobs"].cpu()[b].item() / max(len(greedy[b]), 1) - 1e-2
 
 
-def test_prompt_pass_is_bit_identical_to_stepwise_feeding_bf16(models, monkeypatch):
+@pytest.mark.parametrize("xattn", [False, True])
+def test_prompt_pass_is_bit_identical_to_stepwise_feeding_bf16(models, monkeypatch, xattn):
     """bf16 decode feeds the forced part of the prompts several positions per pass (rows = sequences x positions).  With
     previous-text prompts of different lengths (SOT in the middle of the row, so the no-speech read falls inside a pass),
     ids, cumulative log-probabilities and no-speech probabilities are bit-identical to one-position-per-step feeding."""
-    dims, sd, eng = models("micro256", "bf16", max_batch=16, attn_gain=1.0, eot_boost=3.0)
+    dims, sd, eng = models("micro256", "bf16", max_batch=16, xattn=xattn, attn_gain=1.0, eot_boost=3.0)
     tok = eng.tok
     rng = np.random.default_rng(8)
     mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(60 + s), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000] for s in range(3)])

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 --pmc FETCH_SIZE pass (tools/pmc.sh): per-kernel mean FETCH_SIZE, corrected as
 MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE is in KiB and reports exactly half of the bytes of a wide
-coalesced streaming read: x 1024 x 2).  Writes the cross-attention kernel's figure as JSON for bench.py's `traffic`."""
+coalesced streaming read: x 1024 x 2).  Writes the dominant kernel's figure (argv[3], default the E-stream cross-attention
+kernel) as JSON for bench.py's `traffic`."""
 import csv, collections, glob, json, sys
 d = sys.argv[1]
 f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
@@ -14,7 +15,7 @@ out = {}
 for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
     b = sum(v) / len(v) * 1024 * 2
     print(f"{k[:80]:80s} launches={len(v):5d} hbm_bytes_per_launch={b:16.0f}")
-    if "attn_decode_kernel" in k:
+    if (sys.argv[3] if len(sys.argv) > 3 else "xattn_estream_kernel") in k:
         out = {"kernel": k, "launches": len(v), "hbm_bytes_per_launch": b, "counter": "FETCH_SIZE (KiB) x 1024 x 2",
                "source": "rocprofv3 --pmc FETCH_SIZE, own pass, bench.py --steps 1 --warmup 0 --max-new-tokens 4"}
 if len(sys.argv) > 2 and out:

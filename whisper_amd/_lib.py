@@ -53,6 +53,7 @@ PROTOTYPES = {
     "wx_get_profile": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
     "wx_weight_bytes": (c_i64, [c_vp]),
     "wx_workspace_bytes": (c_i64, [c_vp]),
+    "wx_cross_attention_form": (c_i32, [c_vp]),
 }
 
 _lib = None

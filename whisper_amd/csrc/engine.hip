@@ -308,7 +308,11 @@ int wx_create(const wx_config* cfg, wx_engine** out) {
     e->n_pages_seq = c.n_text_ctx / KV_PAGE;
     e->ld_tok = c.n_text_ctx + 1;
     e->qk_scale = powf((float)HEAD_DIM, -0.25f);
-    e->xattn = e->dt == DT_BF16 && getenv("WX_NO_XATTN") == nullptr;
+    // Cross-attention on the encoder output needs enough rows to fill the chip with one workgroup per (row, key split <= 8): from
+    // 32 windows up it wins (1257 vs 1254 RTFx at 32, 1544 vs 1477 at 48, 1801 vs 1572 at 64, 1937 vs 1643 at 80), below it the K/V
+    // form's (window, head, split) grid does (853 vs 739 at 16).  An engine property, not a per-call choice: a window decodes to
+    // the same ids whatever the batch it is in.  WX_XATTN=1 / WX_NO_XATTN=1 force either form (tests, A/B).
+    e->xattn = e->dt == DT_BF16 && getenv("WX_NO_XATTN") == nullptr && (c.max_batch >= 32 || getenv("WX_XATTN") != nullptr);
     hipError_t r = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
     if (r == hipSuccess) r = hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming);
     if (r == hipSuccess) r = hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming);
@@ -510,8 +514,10 @@ int wx_finalize(wx_engine* e) {
         if ((r = A(&e->crossK, cross_layer * c.n_text_layer * es))) return r;
         if ((r = A(&e->crossV, cross_layer * c.n_text_layer * es))) return r;
     } else {
-        e->x_split = 1;
-        while (e->x_split < 8 && B * e->x_split < 256) e->x_split *= 2;
+        // key splits per row: as many as fit ONE round of workgroups (the stream kernel owns a CU: 256 workgroups), at most 8 (or
+        // WX_XATTN_SPLIT); a function of max_batch only
+        e->x_split = 256 / B; if (e->x_split < 1) e->x_split = 1; if (e->x_split > 8) e->x_split = 8;
+        if (const char* xs = getenv("WX_XATTN_SPLIT")) { const int v = atoi(xs); if (v >= 1 && v <= 8) e->x_split = v; }
         e->x_nt16 = ((T + 15) / 16 + 1) / 2 * 2;
         if ((r = A(&e->enc_frag, (size_t)B * e->x_nt16 * 16 * d * 2))) return r;
         if ((r = A(&e->x_qt, (size_t)B * e->Ht * d * 2))) return r;
@@ -1299,5 +1305,6 @@ int wx_decoder_logits(wx_engine* e, int32_t B, const int32_t* d_tokens, int32_t 
 
 int64_t wx_weight_bytes(wx_engine* e) { return e ? e->weight_bytes : 0; }
 int64_t wx_workspace_bytes(wx_engine* e) { return e ? e->work_bytes : 0; }
+int32_t wx_cross_attention_form(wx_engine* e) { return e && e->xattn ? 1 : 0; }
 
 }  // extern "C"

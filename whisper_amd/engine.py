@@ -100,6 +100,12 @@ class WhisperEngine:
     def workspace_bytes(self) -> int:
         return int(self.lib.wx_workspace_bytes(self.handle))
 
+    @property
+    def cross_form(self) -> str:
+        """"kv": decoder cross-attention on cached per-layer K/V; "encoder_output": on the encoder output itself (bf16 engines
+        with max_batch >= 32; include/whisper_amd.h wx_cross_attention_form)."""
+        return "encoder_output" if int(self.lib.wx_cross_attention_form(self.handle)) == 1 else "kv"
+
     # -- audio ingest ---------------------------------------------------------------------------------------
     def pcm16_to_f32(self, pcm16) -> torch.Tensor:
         """int16 PCM (numpy array or tensor) -> float32 samples in [-1, 1) on the device (x / 32768, converted by the
