@@ -78,6 +78,7 @@ int launch_gemm_khalf(const GemmArgs& g, hipStream_t st);
 int launch_pack_gemm_weight(const void* W, int64_t ldw, int N, int K, void* out, hipStream_t st);
 // K-split factor that fills the chip for a bf16 decode GEMM (M <= DG_MAX_ROWS) whose consumer can add partial tiles; 1 = none.
 int decode_gemm_split(int N, int K);
+bool decode_gemm_split_ok(int K, int s);
 
 // ---- elementwise / norms ---------------------------------------------------------------------------
 int launch_layernorm(const float* x, const float* gamma, const float* beta, void* out, int out_dtype,

@@ -887,7 +887,9 @@ static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, floa
     // tuning hooks (WX_SPLIT_DD / FC2 / QKV / FC1 override the K-split of the four decode GEMM shapes)
     static const int o_dd = getenv("WX_SPLIT_DD") ? atoi(getenv("WX_SPLIT_DD")) : 0, o_fc2 = getenv("WX_SPLIT_FC2") ? atoi(getenv("WX_SPLIT_FC2")) : 0,
                      o_qkv = getenv("WX_SPLIT_QKV") ? atoi(getenv("WX_SPLIT_QKV")) : 0, o_fc1 = getenv("WX_SPLIT_FC1") ? atoi(getenv("WX_SPLIT_FC1")) : 0;
-    const int s_dd = o_dd ? o_dd : decode_gemm_split(d, d), s_fc2 = o_fc2 ? o_fc2 : decode_gemm_split(d, 4 * d),
+    // d x d projections: the split that fills the chip (10 at d = 1280) on the K/V path; 4 on the encoder-output path, where the
+    // q~ launch and the reduce + LayerNorm launches read every partial tile again (decode 874-886 -> 863 ms; 507 -> 509 at batch 16 on K/V)
+    const int s_dd = o_dd ? o_dd : (e->xattn && decode_gemm_split_ok(d, 4) && decode_gemm_split(d, d) > 4) ? 4 : decode_gemm_split(d, d), s_fc2 = o_fc2 ? o_fc2 : decode_gemm_split(d, 4 * d),
               s_qkv = o_qkv ? o_qkv : decode_gemm_split(3 * d, d), s_fc1 = o_fc1 ? o_fc1 : decode_gemm_split(4 * d, d);
     int pend_split = 0; const float* pend_bias = nullptr;       // residual update not yet folded into dx
     auto split_gemm = [&](const void* A, int64_t lda, const void* W, const void* Wpk, int K, int S) {

@@ -627,6 +627,9 @@ int decode_gemm_split(int N, int K) {
     return best;
 }
 
+// whether the decode GEMMs can split K = `K` over `s` workgroups (the slice must be 1..4 chunks of 128, 256 or 320)
+bool decode_gemm_split_ok(int K, int s) { return s >= 1 && K % s == 0 && K / s >= 128 && decode_gemm_cks(K / s) != 0; }
+
 // ---------------------------------------------------------------------------------------------------------
 // fp32 on v_mfma_f32_16x16x4_f32
 // ---------------------------------------------------------------------------------------------------------
