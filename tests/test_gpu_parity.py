@@ -204,6 +204,41 @@ def test_greedy_tokens_bit_exact_fp32(models, name, use_graph):
         assert (t[b, len(init) + int(n[b]):] == tok.eot).all()
 
 
+def test_english_only_vocabulary_greedy_fp32(models):
+    """An English-only checkpoint (51 864 ids: eot 50256, sot 50257, no language tokens): start sequence [sot, no_timestamps],
+    the GPT-2 non-speech suppress table, no language detection -- greedy ids, log-probabilities and no-speech probabilities
+    equal the oracle's in fp32 mode, plain and with the timestamp rules."""
+    dims, sd, eng = models("micro.en", "fp32", eot_boost=3.0)
+    assert dims.n_vocab == 51864 and not ck.is_multilingual(dims.n_vocab)
+    om = wo.OracleWhisper(dims, sd)
+    tok = eng.tok
+    assert (tok.eot, tok.sot) == (50256, 50257)
+    init = eng.initial_tokens(0)
+    assert init == [tok.sot, tok.no_timestamps]
+    sup = wo.suppress_token_ids(tok, ck.non_speech_suppress_ids(dims.n_vocab))
+    assert sorted(eng.suppress_ids) == sorted(sup)
+    mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(60 + s), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000] for s in range(3)])
+    eng.encode_windows(mels)
+    assert eng.detect_language(eng.log_mel(torch.from_numpy(wo.varied_audio(60))), 3000) == 0
+    with torch.no_grad():
+        xa = om.encode(mels)
+        ref = wo.greedy_decode(om, xa, init, tok, sup, max_new_tokens=30)
+    r = eng.decode_greedy(3, init, max_new_tokens=30)
+    t, n = r["tokens"].cpu(), r["n_tokens"].cpu()
+    assert ref["margins"].min() > 1e-3, "fixture argmax is ill-conditioned; pick another seed"
+    assert [t[b, len(init):len(init) + int(n[b])].tolist() for b in range(3)] == ref["tokens"]
+    np.testing.assert_allclose(r["sum_logprobs"].cpu().numpy(), ref["sum_logprobs"], rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(r["no_speech_probs"].cpu().numpy(), ref["no_speech_probs"], rtol=1e-3)
+    init_ts = eng.initial_tokens(0, without_timestamps=False)
+    assert init_ts == [tok.sot]
+    with torch.no_grad():
+        ref_ts = wo.greedy_decode(om, xa, init_ts, tok, sup, max_new_tokens=30, without_timestamps=False)
+    r = eng.decode_greedy(3, init_ts, max_new_tokens=30, without_timestamps=False)
+    t, n = r["tokens"].cpu(), r["n_tokens"].cpu()
+    assert ref_ts["margins"].min() > 1e-3
+    assert [t[b, len(init_ts):len(init_ts) + int(n[b])].tolist() for b in range(3)] == ref_ts["tokens"]
+
+
 def test_greedy_with_timestamp_rules_fp32(models):
     dims, sd, eng = models("micro", "fp32", eot_boost=3.0)
     om = wo.OracleWhisper(dims, sd)

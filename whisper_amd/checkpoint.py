@@ -46,11 +46,17 @@ _NAMED = {
     "base": dict(d=512, h=8, le=6, ld=6, mels=80, vocab=51865),
     "small": dict(d=768, h=12, le=12, ld=12, mels=80, vocab=51865),
     "medium": dict(d=1024, h=16, le=24, ld=24, mels=80, vocab=51865),
+    # English-only checkpoints (GPT-2 vocabulary, 51 864 ids: no language tokens; start sequence [sot] alone)
+    "tiny.en": dict(d=384, h=6, le=4, ld=4, mels=80, vocab=51864),
+    "base.en": dict(d=512, h=8, le=6, ld=6, mels=80, vocab=51864),
+    "small.en": dict(d=768, h=12, le=12, ld=12, mels=80, vocab=51864),
+    "medium.en": dict(d=1024, h=16, le=24, ld=24, mels=80, vocab=51864),
     "large-v3": dict(d=1280, h=20, le=32, ld=32, mels=128, vocab=51866),
     "large-v3-turbo": dict(d=1280, h=20, le=32, ld=4, mels=128, vocab=51866),
     # not an upstream model: a 2-layer, 2-head model with the real context sizes, for fast tests
     "micro": dict(d=128, h=2, le=2, ld=2, mels=80, vocab=51865),
     "micro128": dict(d=128, h=2, le=1, ld=1, mels=128, vocab=51866),
+    "micro.en": dict(d=128, h=2, le=2, ld=2, mels=80, vocab=51864),
     # not an upstream model: widths that are multiples of 256, so a 3-window batch reaches the 256x256 encoder GEMM tiles
     "micro256": dict(d=256, h=4, le=2, ld=2, mels=80, vocab=51865),
 }
