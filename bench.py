@@ -44,7 +44,7 @@ def parse():
     p.add_argument("--batch", type=int, default=64, help="30 s windows per GPU per step")
     p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--max-new-tokens", type=int, default=0, help="0 = upstream sample_len (n_text_ctx // 2)")
-    p.add_argument("--beam", type=int, default=0, help="beam width (0 = greedy); rows = batch x beam must be <= 80 for the fast decode path")
+    p.add_argument("--beam", type=int, default=0, help="beam width (0 = greedy); beam search keeps the split-K decode path up to batch x beam = 80 rows")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real multi-GPU path) | gloo (rehearsal of the N>1 code path)")

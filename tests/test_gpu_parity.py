@@ -314,11 +314,12 @@ def test_long_prompt_fills_the_text_context_fp32(models):
         assert t[b, len(init):len(init) + n[b]].tolist() == ref["tokens"][b]
 
 
-@pytest.mark.parametrize("precision,rows", [("fp32", 96), ("bf16", 72), ("bf16", 80), ("bf16", 96)])
+@pytest.mark.parametrize("precision,rows", [("fp32", 96), ("bf16", 72), ("bf16", 80), ("bf16", 96), ("bf16", 130)])
 def test_large_decode_batches(models, precision, rows):
-    """The split-K decode kernels serve batches of up to 80 rows (5 MFMA row tiles: 64 greedy windows, or 15 windows x 5
-    beams); a larger batch runs the general GEMM / attention kernels.  fp32 ids equal the oracle's, bf16 ids agree wherever
-    the oracle's top-2 margin is comfortable."""
+    """The split-K decode kernels serve up to 80 rows per pass (5 MFMA row tiles: 64 greedy windows, or 15 windows x 5
+    beams); a larger bf16 batch runs as consecutive passes (96 rows = 2 x 48, 130 = 2 x 80 / 50), a larger fp32 batch on the
+    general GEMM / attention kernels.  fp32 ids equal the oracle's, bf16 ids agree wherever the oracle's top-2 margin is
+    comfortable, and a window of the second pass decodes to the same ids in a batch of its own."""
     dims, sd, eng = models("micro", precision, max_batch=rows, eot_boost=3.0)
     om = wo.OracleWhisper(dims, sd)
     tok = eng.tok
@@ -338,6 +339,11 @@ def test_large_decode_batches(models, precision, rows):
                 if ref["margins"][i, b] < 0.15:
                     break
                 assert int(t[b, len(init) + i]) == want
+    if precision == "bf16" and rows > 80:
+        assert eng.cross_form == "encoder_output"
+        eng.encode_windows(mels[rows - 3:])
+        small = eng.decode_greedy(3, init, max_new_tokens=10)["tokens"].cpu()
+        assert torch.equal(small, t[rows - 3:])
 
 
 @pytest.mark.parametrize("name,beam,boost,use_graph", [("micro", 5, 3.0, True), ("micro", 5, 6.0, False), ("tiny", 3, 3.0, True),

@@ -24,8 +24,9 @@ constexpr int HOP = 160;
 constexpr int N_FREQ = 201;
 constexpr int WIN_FRAMES = 3000;  // mel frames per 30 s window
 constexpr int RS_MAX_TAPS = 65536; // resampler filter table (wx_resample_pcm16)
-constexpr int DG_MAX_ROWS = 80;    // rows served by the split-K decode GEMM path (5 MFMA row tiles): 64 greedy windows, or
-                                   // 15 windows x 5 beams (BASELINE configs[3]: 120 windows of a 1 h file over 8 GPUs)
+constexpr int DG_MAX_ROWS = 80;    // rows one pass of the split-K decode GEMM path takes (5 MFMA row tiles): 64 greedy windows, or
+                                   // 15 windows x 5 beams (BASELINE configs[3]: 120 windows of a 1 h file over 8 GPUs); larger greedy
+                                   // batches run as several passes (engine.hip decode_step_bf16)
 
 // ---- GEMM -------------------------------------------------------------------------------------------
 // out[m][n] = epilogue( sum_k A[m][k] * W[n][k] ), A rows addressed as

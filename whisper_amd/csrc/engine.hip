@@ -87,6 +87,8 @@ struct wx_engine {
     float *sum_logprob = nullptr, *no_speech = nullptr, *partial = nullptr, *gpartial = nullptr, *samp_part = nullptr;
     // decoder cross-attention on the encoder output (xattn.hip; bf16 engines, every row whose window has no beams to share with)
     bool xattn = false;
+    int pass_rows = 0;                                       // rows per decode pass of the split-K path: max_batch, or its even share of
+                                                             // ceil(max_batch / DG_MAX_ROWS) passes rounded up to 16 (a function of max_batch only)
     int x_split = 1;                                         // key splits per row: a function of max_batch only (batch invariance)
     void* enc_frag = nullptr;                                // encoder output in MFMA-fragment order [windows][x_nt16][d / 32][64][8] bf16
     int x_nt16 = 0;                                          // 16-key tiles per window in enc_frag (even; zero rows past T)
@@ -497,6 +499,10 @@ int wx_finalize(wx_engine* e) {
         e->suppress = (uint8_t*)p;
     }
     // ---- workspace ----
+    {
+        const int passes = (B + DG_MAX_ROWS - 1) / DG_MAX_ROWS;
+        e->pass_rows = passes <= 1 ? B : (((B + passes - 1) / passes + 15) / 16) * 16;
+    }
     const int64_t rows = (int64_t)B * T;
     auto A = [&](void** p, size_t bytes) { return dev_alloc(e, p, bytes, false); };
     if ((r = A(&e->xpad1, (size_t)B * (WIN_FRAMES + 2) * e->c_pad * es))) return r;
@@ -516,7 +522,7 @@ int wx_finalize(wx_engine* e) {
     } else {
         // key splits per row: as many as fit ONE round of workgroups (the stream kernel owns a CU: 256 workgroups), at most 8 (or
         // WX_XATTN_SPLIT); a function of max_batch only
-        e->x_split = 256 / B; if (e->x_split < 1) e->x_split = 1; if (e->x_split > 8) e->x_split = 8;
+        e->x_split = 256 / e->pass_rows; if (e->x_split < 1) e->x_split = 1; if (e->x_split > 8) e->x_split = 8;
         if (const char* xs = getenv("WX_XATTN_SPLIT")) { const int v = atoi(xs); if (v >= 1 && v <= 8) e->x_split = v; }
         e->x_nt16 = ((T + 15) / 16 + 1) / 2 * 2;
         if ((r = A(&e->enc_frag, (size_t)B * e->x_nt16 * 16 * d * 2))) return r;
@@ -691,7 +697,7 @@ static int project_cross_kv(wx_engine* e, int B, hipStream_t st) {
 // K/V stream) and batches beyond the split-K decode path.  Must be called outside graph capture (it may allocate).
 static int ensure_cross_kv(wx_engine* e, int rows, int beam_n, hipStream_t st) {
     if (!e->xattn) return 0;                                   // projected by wx_encode
-    if (beam_n <= 1 && rows <= DG_MAX_ROWS) return 0;          // the E-stream path needs no K/V
+    if (beam_n == 0 || (beam_n == 1 && rows <= DG_MAX_ROWS)) return 0;      // the E-stream path needs no K/V
     if (e->cross_kv_B >= e->encoded_B && e->crossK) return 0;
     return project_cross_kv(e, e->encoded_B, st);
 }
@@ -984,16 +990,24 @@ static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, floa
     return 0;
 }
 
+// More rows than the split-K kernels take at once (DG_MAX_ROWS) run as consecutive passes of e->pass_rows rows each -- the rows of
+// a batch do not interact before the sampler, and the pass size is a function of max_batch only -- so a large max_batch costs its
+// share of launches, not a fall to the general kernels.
 static int decode_step_bf16(wx_engine* e, int B, const SamplerArgs* sa, hipStream_t st) {
-    int r = decode_layers_bf16(e, 0, B, e->gpartial, e->partial, true, st);
-    if (r) return r;
+    for (int b0 = 0; b0 < B; b0 += e->pass_rows) {
+        const int rows = B - b0 < e->pass_rows ? B - b0 : e->pass_rows;
+        int r = decode_layers_bf16(e, b0, rows, e->gpartial, e->partial, b0 == 0, st);
+        if (r) return r;
+    }
     if (sa) WX_TRY(launch_sampler(*sa, st));
     return 0;
 }
 
-// decoder layers for B rows at position *d_pos, then the greedy sampler (sa) or nothing (the beam step follows)
+// decoder layers for B rows at position *d_pos, then the greedy sampler (sa) or nothing (the beam step follows).
+// bf16 split-K path: up to DG_MAX_ROWS rows per pass; greedy / sampling batches beyond that in several passes; beam search
+// beyond that (its rows share K/V streams and cache nodes across the whole batch) on the general kernels.
 static int decode_step(wx_engine* e, int B, const SamplerArgs* sa, hipStream_t st) {
-    return (e->dt == DT_BF16 && B <= DG_MAX_ROWS) ? decode_step_bf16(e, B, sa, st) : decode_step_f32(e, B, sa, st);
+    return (e->dt == DT_BF16 && (B <= DG_MAX_ROWS || e->beam_n == 0)) ? decode_step_bf16(e, B, sa, st) : decode_step_f32(e, B, sa, st);
 }
 
 static SamplerArgs make_sampler(wx_engine* e, int B, const wx_decode_opts& o, int forced) {
