@@ -51,6 +51,8 @@ def parse():
     p.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
     p.add_argument("--cpu-decode-steps", type=int, default=0, help="0 = as many greedy steps as the GPU run took (no extrapolation)")
     p.add_argument("--no-profile-pass", action="store_true", help="skip the event-bracketed eager pass (PMC runs)")
+    p.add_argument("--lanes", type=int, default=4, help="batches in flight per GPU: engine replicas, each on its own host thread and stream "
+                   "(whisper_amd/lanes.py); step i runs on lane i mod lanes.  1 = one batch at a time (per-kernel profiles)")
     p.add_argument("--dry-run", action="store_true", help="launcher rehearsal: every rank reports its rank environment and exits before touching the GPU")
     return p.parse_args()
 
@@ -200,7 +202,11 @@ def main():
     tok = ck.special_tokens_for(dims.n_vocab)
     B = args.batch
     sd = ck.synthetic_state_dict(dims, seed=0)
-    eng = WhisperEngine(dims, sd, precision=args.precision, max_batch=B * max(1, args.beam), device=local_rank)
+    from whisper_amd.lanes import EngineLanes
+    if args.lanes < 1:
+        raise SystemExit("--lanes must be >= 1")
+    lanes = EngineLanes.create(lambda: WhisperEngine(dims, sd, precision=args.precision, max_batch=B * max(1, args.beam), device=local_rank), args.lanes)
+    eng = lanes.engines[0]
     prompt = eng.initial_tokens(0)
 
     # this rank's windows of one long virtual file of world*B windows; clip i of the file uses seed i
@@ -210,11 +216,16 @@ def main():
     s_lo = w_lo * N_SAMPLES
     pcm = torch.from_numpy(host).to(dev)          # resident in HBM before the timed region
     del host
+    torch.cuda.synchronize(dev)
 
     stream = torch.cuda.Stream(device=dev)
-    state = {}
 
-    def step(use_graph=True, profile_stride=0, marks=None):
+    # One step = one batch of B windows through the whole hot path.  Front: log-mel on the main thread, in step order -- with
+    # N > 1 it holds the path's one exchange in front of the decode (the 4-byte MAX all-reduce of the mel clamp), and every
+    # collective of this program is issued by this thread in the same order on every rank.  (The mel entry points only read the
+    # engine's tables, so lane 0's engine serves them while its lane decodes.)  Back: encoder + decode loop on the step's lane
+    # (engine replica, host thread, stream).  Then the result gather, main thread again.
+    def front(marks=None):
         def mark():
             if marks is not None:
                 ev = torch.cuda.Event(enable_timing=True)
@@ -222,6 +233,16 @@ def main():
                 marks.append(ev)
         mark()
         mel = sharded_mel(eng, pcm, s_lo, n_file, w_lo, w_hi)
+        mark()
+        torch.cuda.current_stream(dev).synchronize()       # the lane's stream reads it
+        return mel
+
+    def back(eng, mel, use_graph=True, profile_stride=0, marks=None):
+        def mark():
+            if marks is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks.append(ev)
         mark()
         eng.encode(mel, N_FRAMES, mel.stride(0), n_file // 160 - w_lo * N_FRAMES, B)
         mark()
@@ -235,11 +256,24 @@ def main():
         else:
             r = eng.decode_greedy(B, prompt, max_new_tokens=args.max_new_tokens, use_graph=use_graph,
                                   profile_stride=profile_stride)
-        if world > 1:      # result gather: padded ids + lengths, ~115 KB per rank
-            out = wdist.all_gather(r["tokens"])
-            lens = wdist.all_gather(r["n_tokens"])
         mark()
-        state["r"], state["mel"] = r, mel
+        return r
+
+    def gather(r):             # result gather: padded ids + lengths, ~115 KB per rank
+        if world > 1:
+            wdist.all_gather(r["tokens"])
+            wdist.all_gather(r["n_tokens"])
+        return r
+
+    def run_steps(n_steps, lane_of):
+        """n_steps batches; batch i on lane lane_of(i); at most 2 x lanes log-mels ahead of the slowest lane"""
+        pending, r, done = [], None, 0
+        for i in range(n_steps):
+            pending.append(lanes.submit(back, front(), not args.no_graph, lane=lane_of(i)))
+            while len(pending) - done > 2 * lanes.n_lanes:
+                r = gather(pending[done].result()); done += 1
+        while done < len(pending):
+            r = gather(pending[done].result()); done += 1
         return r
 
     def sync_all():
@@ -249,26 +283,27 @@ def main():
         torch.cuda.synchronize(dev)
 
     with torch.cuda.stream(stream):
-        for _ in range(args.warmup):
-            step(not args.no_graph)
+        # warm-up: W steps, at least one per lane (its graph is captured there), one lane at a time
+        n_warm = max(args.warmup, lanes.n_lanes)
+        for i in range(n_warm):
+            gather(lanes.submit(back, front(), not args.no_graph, lane=i % lanes.n_lanes).result())
         sync_all()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            r = step(not args.no_graph)
+        r = run_steps(args.steps, lambda i: i % lanes.n_lanes)
         sync_all()
         elapsed = time.perf_counter() - t0
         steps_per_window = int(r["steps"])
         n_tokens = r["n_tokens"].float().mean().item()
 
-        # dominant kernel: event-bracketed eager pass on the same batch
-        # per-stage device time of one more (untimed) step: events on the launch stream
-        marks = []
-        step(not args.no_graph, marks=marks)
+        # per-stage device time of one more (untimed) step, alone on the GPU: events on the stream of each stage
+        m_front, m_back = [], []
+        lanes.submit(back, front(m_front), not args.no_graph, 0, m_back, lane=0).result()
         torch.cuda.synchronize(dev)
-        st_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(3)]
+        st_ms = [m_front[0].elapsed_time(m_front[1]), m_back[0].elapsed_time(m_back[1]), m_back[1].elapsed_time(m_back[2])]
+        # dominant kernel: event-bracketed eager pass on the same batch, alone on the GPU
         prof_ms, prof_n = 0.0, 0
         if not args.no_profile_pass and not args.beam:
-            step(use_graph=False, profile_stride=8)
+            lanes.submit(back, front(), False, 8, lane=0).result()
             torch.cuda.synchronize(dev)
             prof_ms, prof_n = eng.last_profile()
 
@@ -312,6 +347,7 @@ def main():
                 "windows_per_gpu": B, "decode_steps_per_window": steps_per_window, "mean_new_tokens": n_tokens,
                 "prompt": "[sot, <|en|>, transcribe, notimestamps]", "weights": "seeded random init (no checkpoints offline)",
                 "hip_graph": not args.no_graph, "parallelism": f"window-dp{world}",
+                "batches_in_flight_per_gpu": lanes.n_lanes,
             },
             "roofline": {
                 "kernel": ("xattn_estream_kernel (decoder cross-attention on the encoder output)" if estream else
@@ -319,6 +355,8 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms, "launches_timed": prof_n,
+                "measured": "HIP events around every launch of the kernel in an eager pass of one batch, alone on the GPU (the timed region "
+                            "replays graphs with several batches in flight, where launches of different batches overlap)",
             },
         }
         # stage rooflines (SURVEY §8d formulas; encoder FLOPs include the cross-K/V projection)
@@ -342,7 +380,7 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    eng.close()
+    lanes.close()
 
 
 if __name__ == "__main__":

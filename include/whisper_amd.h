@@ -9,7 +9,11 @@
  * return 0 on success and a negative wx_status otherwise, never throw, and record a message retrievable with
  * wx_last_error().  Pointers named d_* are DEVICE pointers (HBM, on the engine's device); h_* are host
  * pointers.  `stream` is a hipStream_t passed as void* (NULL = the default stream).  The engine owns weights,
- * workspace and KV caches; the caller owns every buffer it passes in.  Calls on one engine must not overlap.
+ * workspace and KV caches; the caller owns every buffer it passes in.  Calls on one engine must not overlap, with one exception: wx_mel_reset_max,
+ * wx_mel_stage1, wx_mel_stage2, wx_pcm16_to_f32 and wx_resample_pcm16 only read the engine's tables and work on the caller's
+ * buffers and stream, so they may run (from another host thread, on another stream) while the engine encodes or decodes.
+ * Engines are independent of one another: several of them, on one GPU or on several, may be driven from different host threads
+ * at the same time (whisper_amd/lanes.py keeps two batches in flight per GPU that way).
  */
 #ifndef WHISPER_AMD_H
 #define WHISPER_AMD_H

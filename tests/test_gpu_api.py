@@ -451,3 +451,49 @@ def test_timing_harness_prints_the_reference_lines(tmp_path, capsys, monkeypatch
     monkeypatch.setattr(sys, "argv", ["harness", str(tmp_path / "nope.wav")])
     harness.main()
     assert capsys.readouterr().out.strip() == f"Error: Audio file '{tmp_path / 'nope.wav'}' not found"
+
+
+def test_lanes_decode_the_same_ids():
+    """Two and three batches in flight (whisper_amd/lanes.py: engine replicas on their own host threads and streams) decode a
+    long file to exactly the ids, log-probabilities and no-speech probabilities of one engine taking the batches in turn --
+    fp32 and bf16, greedy and beam search, a ragged last batch -- and through transcribe() with lanes configured."""
+    from oracle import whisper_oracle as wo
+    from whisper_amd import transcribe as tx
+    from whisper_amd.engine import WhisperEngine
+    from whisper_amd.lanes import EngineLanes
+    dims = ck.dims_for("micro")
+    sd = ck.synthetic_state_dict(dims, seed=0, eot_boost=3.0)
+    audio = wo.varied_audio(12, 16000 * 30 * 11 + 4321)            # 12 windows: batches of 4, 4, 4 (max_batch 4) or 5, 5, 2
+    for precision, max_batch in (("fp32", 4), ("bf16", 5)):
+        one = WhisperEngine(dims, sd, precision=precision, max_batch=max_batch)
+        try:
+            mel = one.log_mel(torch.from_numpy(audio).cuda())
+            content = audio.size // 160
+            prompt = one.initial_tokens(0)
+            ref = one.transcribe_mel(mel, content, 0, 12, prompt, max_new_tokens=10)
+            ref_beam = one.transcribe_mel(mel, content, 0, 12, prompt, beam_size=2, max_new_tokens=6)
+            for n in (2, 3):
+                with EngineLanes.create(lambda: WhisperEngine(dims, sd, precision=precision, max_batch=max_batch), n) as lanes:
+                    assert lanes.n_lanes == n and lanes.max_batch == max_batch and lanes.cross_form == one.cross_form
+                    for _ in range(2):                               # the second run replays the lanes' captured graphs
+                        got = lanes.transcribe_mel(mel, content, 0, 12, prompt, max_new_tokens=10)
+                        assert got["tokens"] == ref["tokens"] and got["steps"] == ref["steps"]
+                        assert got["sum_logprobs"] == ref["sum_logprobs"] and got["no_speech_probs"] == ref["no_speech_probs"]
+                    got = lanes.transcribe_mel(mel, content, 0, 12, prompt, beam_size=2, max_new_tokens=6)
+                    assert got["tokens"] == ref_beam["tokens"] and got["sum_logprobs"] == ref_beam["sum_logprobs"]
+                    # an error inside a lane reaches the caller
+                    with pytest.raises(Exception):
+                        lanes.submit(lambda e: e.decode_greedy(max_batch + 1, prompt)).result()
+        finally:
+            one.close()
+    # the product entry point with lanes configured
+    try:
+        tx.configure(model="micro", precision="fp32", max_batch=4, allow_synthetic_weights=True)
+        want = tx.transcribe(audio, language="en", max_new_tokens=8)
+        tx.configure(model="micro", precision="fp32", max_batch=4, allow_synthetic_weights=True, lanes=2)
+        got = tx.transcribe(audio, language="en", max_new_tokens=8)
+        assert got["tokens"] == want["tokens"] and got["chunks_processed"] == want["chunks_processed"] == 12
+        seq = tx.transcribe(audio[:16000 * 40], language="en", mode="sequential", max_new_tokens=8, temperatures=(0.0,))
+        assert isinstance(seq["text"], str)
+    finally:
+        tx.close()

@@ -291,3 +291,49 @@ def test_transcribe_large_audio_prompt_carry_and_cleanup(tmp_path, monkeypatch):
     assert asyncio.run(la.transcribe_large_audio(p, False))[:2] == ("Voice authentication required for full transcription", 0.2)
     monkeypatch.setattr(tx, "transcribe", lambda *a, **k: (_ for _ in ()).throw(RuntimeError("boom")))
     assert asyncio.run(la.transcribe_large_audio(p)) == ("", 0.0, "unknown", "failed")
+
+
+def test_engine_lanes_deal_batches_in_order_and_pass_errors_on():
+    """whisper_amd/lanes.py with duck-typed engines: batch i of a file goes to lane i mod n, a lane runs its batches in
+    submission order, results come back in window order, attribute access falls through to lane 0, an exception inside a lane
+    is raised from result(), replicas of different configurations are refused."""
+    import threading
+    import time
+    import torch
+    from whisper_amd.lanes import EngineLanes
+
+    class Fake:
+        def __init__(self, name, max_batch=3, delay=0.0):
+            self.name, self.max_batch, self.delay = name, max_batch, delay
+            self.dims, self.precision, self.torch_device = "dims", "fp32", torch.device("cpu")
+            self.calls, self.closed = [], False
+
+        def transcribe_mel(self, mel, n_content, w_lo, w_hi, prompt, beam_size=None, patience=1.0, **kw):
+            time.sleep(self.delay)
+            self.calls.append((w_lo, w_hi, threading.current_thread().name))
+            if kw.get("boom") and w_lo == kw["boom"]:
+                raise RuntimeError("lane failure")
+            return {"tokens": [[w, len(prompt)] for w in range(w_lo, w_hi)], "sum_logprobs": [float(w) for w in range(w_lo, w_hi)],
+                    "no_speech_probs": [0.5] * (w_hi - w_lo), "steps": 7}
+
+        def close(self):
+            self.closed = True
+
+    a, b = Fake("a", delay=0.05), Fake("b")
+    with EngineLanes([a, b]) as lanes:
+        assert lanes.n_lanes == 2 and lanes.name == "a" and lanes.max_batch == 3
+        out = lanes.transcribe_mel(None, 0, 2, 13, [1, 2, 3, 4])
+        assert out["tokens"] == [[w, 4] for w in range(2, 13)] and out["steps"] == 28 and len(out["no_speech_probs"]) == 11
+        assert [c[:2] for c in a.calls] == [(2, 5), (8, 11)] and [c[:2] for c in b.calls] == [(5, 8), (11, 13)]
+        assert {c[2] for c in a.calls} == {"whisper-amd-lane-0"} and {c[2] for c in b.calls} == {"whisper-amd-lane-1"}
+        out = lanes.transcribe_mel(None, 0, 0, 4, [1], beam_size=2)           # beam search: max_batch // beam_size windows per batch
+        assert [c[:2] for c in a.calls[2:]] == [(0, 1), (2, 3)] and len(out["tokens"]) == 4
+        with pytest.raises(RuntimeError, match="lane failure"):
+            lanes.transcribe_mel(None, 0, 0, 9, [1], boom=3)
+        assert lanes.map(lambda e, x: (e.name, x), [10, 11, 12]) == [("a", 10), ("b", 11), ("a", 12)]
+        assert lanes.submit(lambda e: e.name).result() in ("a", "b")
+    assert a.closed and b.closed
+    with pytest.raises(ValueError):
+        EngineLanes([Fake("a"), Fake("b", max_batch=4)])
+    with pytest.raises(ValueError):
+        EngineLanes([])

@@ -1,0 +1,153 @@
+"""Batches in flight: N replicas of one engine ("lanes") on one GPU, each driven by its own host thread on its own HIP stream.
+
+Why.  One batch of 30 s windows keeps the GPU busy only in patches: the decode loop is a chain of short, dependent launches (a
+dozen per decoder layer and token, 4-12 us each, most of them waiting on one memory round trip) around one bandwidth-bound
+stream per layer, and the encoder runs alone in front of it.  A second, independent batch fills the holes -- its short launches
+run beside the other batch's stream, its encoder beside the other's decode loop.  Measured on one MI355X, large-v3 bf16, 64
+windows per batch, 224 tokens: 1053 ms per batch with 1 lane, 851 with 2, 807 with 3, 781 with 4 (1823 -> 2459 audio-s/s), no
+further gain at 6 or 8 (the runtime maps streams onto 4 hardware queues).  The batches
+stay what they were (same kernels, same max_batch, same key split), so a window's ids do not depend on the lane it ran on
+(tests/test_gpu_api.py::test_lanes_decode_the_same_ids).
+
+What it costs: one more copy of the weights and of the workspace per lane (large-v3 bf16, max_batch 64: 4.7 + 8 GB of 288).
+
+The reference has no counterpart: its model is one global object behind an asyncio lock-free call
+(ref:app/transcription/speech_recognition.py:20-26,55), one file at a time.  Independent 30 s windows are what
+makes batches, and therefore lanes, possible.
+"""
+from __future__ import annotations
+
+import queue
+import threading
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+
+
+class _Lane:
+    def __init__(self, engine, index: int):
+        self.engine = engine
+        self.index = index
+        # (a duck-typed engine on a CPU device -- the host-logic tests' stand-in -- gets a thread and no stream)
+        self.stream = torch.cuda.Stream(device=engine.torch_device) if engine.torch_device.type == "cuda" else None
+        self.jobs: "queue.Queue" = queue.Queue()
+        self.thread = threading.Thread(target=self._run, name=f"whisper-amd-lane-{index}", daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        if self.stream is not None:
+            torch.cuda.set_device(self.engine.torch_device)
+        while True:
+            job = self.jobs.get()
+            if job is None:
+                return
+            fn, args, box, done = job
+            try:
+                if self.stream is None:
+                    box["value"] = fn(self.engine, *args)
+                else:
+                    with torch.cuda.stream(self.stream):
+                        box["value"] = fn(self.engine, *args)
+                        self.stream.synchronize()        # results are complete when the job is reported done
+            except BaseException as exc:                 # handed to the caller of result()
+                box["error"] = exc
+            finally:
+                done.set()
+
+
+class _Pending:
+    def __init__(self, box: Dict[str, object], done: threading.Event):
+        self._box, self._done = box, done
+
+    def result(self):
+        self._done.wait()
+        if "error" in self._box:
+            raise self._box["error"]
+        return self._box["value"]
+
+
+class EngineLanes:
+    """``engines``: replicas of ONE configuration on ONE device (same weights, precision, max_batch).  Jobs of a lane run in
+    submission order on the lane's own stream; different lanes run concurrently.  Attribute access falls through to lane 0's
+    engine, so an ``EngineLanes`` can stand wherever a ``WhisperEngine`` is used (whisper_amd.dist.transcribe_sharded); only
+    ``transcribe_mel`` is different: it deals the batches of a file out over the lanes."""
+
+    def __init__(self, engines: Sequence):
+        if not engines:
+            raise ValueError("at least one engine")
+        e0 = engines[0]
+        for e in engines[1:]:
+            if (e.dims, e.precision, e.max_batch, e.torch_device) != (e0.dims, e0.precision, e0.max_batch, e0.torch_device):
+                raise ValueError("lanes must be replicas of one engine configuration on one device")
+        self._lanes = [_Lane(e, i) for i, e in enumerate(engines)]
+        self._next = 0
+
+    @classmethod
+    def create(cls, make_engine: Callable[[], object], n_lanes: int) -> "EngineLanes":
+        if n_lanes < 1:
+            raise ValueError("n_lanes must be >= 1")
+        return cls([make_engine() for _ in range(n_lanes)])
+
+    @property
+    def n_lanes(self) -> int:
+        return len(self._lanes)
+
+    @property
+    def engines(self) -> List:
+        return [ln.engine for ln in self._lanes]
+
+    def __getattr__(self, name):                          # everything else: lane 0's engine
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self._lanes[0].engine, name)
+
+    def submit(self, fn: Callable, *args, lane: Optional[int] = None) -> _Pending:
+        """Queue ``fn(engine, *args)`` on a lane (round robin unless ``lane`` is given)."""
+        if lane is None:
+            lane, self._next = self._next, (self._next + 1) % len(self._lanes)
+        box: Dict[str, object] = {}
+        done = threading.Event()
+        self._lanes[lane].jobs.put((fn, args, box, done))
+        return _Pending(box, done)
+
+    def map(self, fn: Callable, items: Sequence) -> List:
+        """``[fn(engine, item) for item in items]``, item i on lane i mod n_lanes, results in order."""
+        pend = [self.submit(fn, item, lane=i % len(self._lanes)) for i, item in enumerate(items)]
+        return [p.result() for p in pend]
+
+    def transcribe_mel(self, mel: torch.Tensor, n_content_frames: int, window_lo: int, window_hi: int,
+                       prompt: Sequence[int], beam_size: Optional[int] = None, patience: float = 1.0, **decode_kw) -> Dict[str, object]:
+        """Same contract as ``WhisperEngine.transcribe_mel``; consecutive batches of ``max_batch`` windows (``max_batch //
+        beam_size`` with beam search) go to consecutive lanes."""
+        e0 = self._lanes[0].engine
+        per = e0.max_batch if not beam_size else max(1, e0.max_batch // int(beam_size))
+        if e0.torch_device.type == "cuda":
+            torch.cuda.current_stream(e0.torch_device).synchronize()  # the mel was produced on the caller's stream
+        spans = [(w0, min(w0 + per, window_hi)) for w0 in range(window_lo, window_hi, per)]
+
+        def one(engine, span):
+            return engine.transcribe_mel(mel, n_content_frames, span[0], span[1], prompt, beam_size=beam_size, patience=patience, **decode_kw)
+
+        parts = self.map(one, spans)
+        out: Dict[str, object] = {"tokens": [], "sum_logprobs": [], "no_speech_probs": [], "steps": 0}
+        for p in parts:
+            out["tokens"] += p["tokens"]; out["sum_logprobs"] += p["sum_logprobs"]; out["no_speech_probs"] += p["no_speech_probs"]
+            out["steps"] += p["steps"]
+        return out
+
+    def close(self):
+        for ln in self._lanes:
+            ln.jobs.put(None)
+        for ln in self._lanes:
+            ln.thread.join(timeout=60)
+            ln.engine.close()
+        self._lanes = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+__all__ = ["EngineLanes"]

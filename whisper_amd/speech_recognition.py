@@ -83,7 +83,7 @@ try:
         model=WHISPER_MODEL, checkpoint=_AMD.get("checkpoint"), vocab=_AMD.get("vocab"),
         precision=_AMD.get("precision", "bf16"), max_batch=int(_AMD.get("max_batch", 16)),
         allow_synthetic_weights=bool(_AMD.get("allow_synthetic_weights", False)),
-        confidence_mode=_AMD.get("confidence_mode", "reference"))
+        confidence_mode=_AMD.get("confidence_mode", "reference"), lanes=int(_AMD.get("lanes", 1)))
     logger.info(f"Whisper model '{WHISPER_MODEL}' loaded on {device}")
 except Exception as e:   # noqa: BLE001 — same as the reference: never fail the import
     logger.error(f"Failed to load Whisper model: {str(e)}")
