@@ -205,7 +205,8 @@ def main():
     from whisper_amd.lanes import EngineLanes
     if args.lanes < 1:
         raise SystemExit("--lanes must be >= 1")
-    lanes = EngineLanes.create(lambda: WhisperEngine(dims, sd, precision=args.precision, max_batch=B * max(1, args.beam), device=local_rank), args.lanes)
+    lanes = EngineLanes.create(lambda n: WhisperEngine(dims, sd, precision=args.precision, max_batch=B * max(1, args.beam), device=local_rank, n_lanes=n),
+                               args.lanes)
     eng = lanes.engines[0]
     prompt = eng.initial_tokens(0)
 

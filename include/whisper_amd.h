@@ -48,6 +48,11 @@ typedef struct {
     /* special tokens (multilingual layout) */
     int32_t tok_eot, tok_sot, tok_translate, tok_transcribe, tok_sot_prev, tok_sot_lm;
     int32_t tok_no_speech, tok_no_timestamps, tok_timestamp_begin, tok_blank;
+    int32_t n_lanes;        /* engines that will share this GPU at the same time (whisper_amd/lanes.py keeps several batches in flight);
+                               0 or 1 = this engine has the GPU to itself.  Sizes the grid of the decoder's cross-attention stream
+                               (key splits per row = ceil(256 CUs / (n_lanes x rows per pass)), at most 8): a launch that fills every CU
+                               finishes one batch sooner, one that leaves CUs to the other lanes finishes all of them sooner.  A
+                               property of the engine like max_batch: results do not depend on the batch at hand. */
 } wx_config;
 
 /* Decode options: the subset of openai-whisper DecodingOptions the reference's call can reach

@@ -42,7 +42,7 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
         '  if (wx_create(0, &e) >= 0) return 2;\n'
         '  if (wx_create(&cfg, &e) >= 0) return 3;          /* all-zero dims are rejected before any HIP call */\n'
         '  if (wx_finalize(0) >= 0) return 4;\n'
-        '  if (sizeof(wx_config) != 23 * 4 || sizeof(wx_decode_opts) != 9 * 4) return 5;\n'
+        '  if (sizeof(wx_config) != 24 * 4 || sizeof(wx_decode_opts) != 9 * 4) return 5;\n'
         '  printf("%s\\n", wx_last_error());\n  return 0;\n}\n')
     exe = tmp_path / "cabi"
     libdir = os.path.dirname(_lib.LIB_PATH)

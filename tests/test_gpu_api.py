@@ -464,28 +464,37 @@ def test_lanes_decode_the_same_ids():
     dims = ck.dims_for("micro")
     sd = ck.synthetic_state_dict(dims, seed=0, eot_boost=3.0)
     audio = wo.varied_audio(12, 16000 * 30 * 11 + 4321)            # 12 windows: batches of 4, 4, 4 (max_batch 4) or 5, 5, 2
-    for precision, max_batch in (("fp32", 4), ("bf16", 5)):
-        one = WhisperEngine(dims, sd, precision=precision, max_batch=max_batch)
-        try:
-            mel = one.log_mel(torch.from_numpy(audio).cuda())
-            content = audio.size // 160
-            prompt = one.initial_tokens(0)
-            ref = one.transcribe_mel(mel, content, 0, 12, prompt, max_new_tokens=10)
-            ref_beam = one.transcribe_mel(mel, content, 0, 12, prompt, beam_size=2, max_new_tokens=6)
-            for n in (2, 3):
-                with EngineLanes.create(lambda: WhisperEngine(dims, sd, precision=precision, max_batch=max_batch), n) as lanes:
-                    assert lanes.n_lanes == n and lanes.max_batch == max_batch and lanes.cross_form == one.cross_form
-                    for _ in range(2):                               # the second run replays the lanes' captured graphs
-                        got = lanes.transcribe_mel(mel, content, 0, 12, prompt, max_new_tokens=10)
-                        assert got["tokens"] == ref["tokens"] and got["steps"] == ref["steps"]
-                        assert got["sum_logprobs"] == ref["sum_logprobs"] and got["no_speech_probs"] == ref["no_speech_probs"]
-                    got = lanes.transcribe_mel(mel, content, 0, 12, prompt, beam_size=2, max_new_tokens=6)
-                    assert got["tokens"] == ref_beam["tokens"] and got["sum_logprobs"] == ref_beam["sum_logprobs"]
-                    # an error inside a lane reaches the caller
-                    with pytest.raises(Exception):
-                        lanes.submit(lambda e: e.decode_greedy(max_batch + 1, prompt)).result()
-        finally:
-            one.close()
+    prompt = None
+    for precision, max_batch, xattn in (("fp32", 4, False), ("bf16", 5, False), ("bf16", 5, True)):
+        for n in (2, 3):
+            # (the key split of the cross-attention stream depends on n_lanes: the single-engine reference is built with the same n_lanes)
+            if xattn:
+                os.environ["WX_XATTN"] = "1"            # cross-attention on the encoder output below 32 rows too
+            try:
+                one = WhisperEngine(dims, sd, precision=precision, max_batch=max_batch, n_lanes=n)
+                lanes = EngineLanes.create(lambda k: WhisperEngine(dims, sd, precision=precision, max_batch=max_batch, n_lanes=k), n)
+            finally:
+                os.environ.pop("WX_XATTN", None)
+            try:
+                assert one.cross_form == ("encoder_output" if xattn else "kv")
+                mel = one.log_mel(torch.from_numpy(audio).cuda())
+                content = audio.size // 160
+                prompt = one.initial_tokens(0)
+                ref = one.transcribe_mel(mel, content, 0, 12, prompt, max_new_tokens=10)
+                ref_beam = one.transcribe_mel(mel, content, 0, 12, prompt, beam_size=2, max_new_tokens=6)
+                assert lanes.n_lanes == n and lanes.max_batch == max_batch and lanes.cross_form == one.cross_form
+                for _ in range(2):                               # the second run replays the lanes' captured graphs
+                    got = lanes.transcribe_mel(mel, content, 0, 12, prompt, max_new_tokens=10)
+                    assert got["tokens"] == ref["tokens"] and got["steps"] == ref["steps"]
+                    assert got["sum_logprobs"] == ref["sum_logprobs"] and got["no_speech_probs"] == ref["no_speech_probs"]
+                got = lanes.transcribe_mel(mel, content, 0, 12, prompt, beam_size=2, max_new_tokens=6)
+                assert got["tokens"] == ref_beam["tokens"] and got["sum_logprobs"] == ref_beam["sum_logprobs"]
+                # an error inside a lane reaches the caller
+                with pytest.raises(Exception):
+                    lanes.submit(lambda e: e.decode_greedy(max_batch + 1, prompt)).result()
+            finally:
+                one.close()
+                lanes.close()
     # the product entry point with lanes configured
     try:
         tx.configure(model="micro", precision="fp32", max_batch=4, allow_synthetic_weights=True)

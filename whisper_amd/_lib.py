@@ -17,7 +17,7 @@ class WxConfig(ctypes.Structure):
         "n_vocab", "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer",
         "precision", "max_batch", "device",
         "tok_eot", "tok_sot", "tok_translate", "tok_transcribe", "tok_sot_prev", "tok_sot_lm",
-        "tok_no_speech", "tok_no_timestamps", "tok_timestamp_begin", "tok_blank")]
+        "tok_no_speech", "tok_no_timestamps", "tok_timestamp_begin", "tok_blank", "n_lanes")]
 
 
 class WxDecodeOpts(ctypes.Structure):

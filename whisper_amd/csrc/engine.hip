@@ -522,7 +522,14 @@ int wx_finalize(wx_engine* e) {
     } else {
         // key splits per row: as many as fit ONE round of workgroups (the stream kernel owns a CU: 256 workgroups), at most 8 (or
         // WX_XATTN_SPLIT); a function of max_batch only
-        e->x_split = 256 / e->pass_rows; if (e->x_split < 1) e->x_split = 1; if (e->x_split > 8) e->x_split = 8;
+        // (with n_lanes engines sharing the GPU, one round of THEIR workgroups together: large-v3 x 64 windows, 4 lanes: 2447 / 2552 /
+        // 2652 / 2723 RTFx at 4 / 3 / 2 / 1 splits -- the stream kernel owns its CU's registers, so a launch that fills the chip
+        // stalls every other lane's short launches for its whole duration)
+        {
+            const int share = (c.n_lanes > 1 ? c.n_lanes : 1) * e->pass_rows;
+            e->x_split = (256 + share - 1) / share;
+        }
+        if (e->x_split < 1) e->x_split = 1; if (e->x_split > 8) e->x_split = 8;
         if (const char* xs = getenv("WX_XATTN_SPLIT")) { const int v = atoi(xs); if (v >= 1 && v <= 8) e->x_split = v; }
         e->x_nt16 = ((T + 15) / 16 + 1) / 2 * 2;
         if ((r = A(&e->enc_frag, (size_t)B * e->x_nt16 * 16 * d * 2))) return r;

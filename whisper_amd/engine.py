@@ -35,9 +35,11 @@ def _ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
 class WhisperEngine:
     def __init__(self, dims: ModelDims, state_dict: Dict[str, torch.Tensor], precision: str = "bf16",
                  max_batch: int = 8, device: int = 0, suppress_ids: Optional[Sequence[int]] = None,
-                 mel_filters: Optional[np.ndarray] = None):
+                 mel_filters: Optional[np.ndarray] = None, n_lanes: int = 1):
         """``mel_filters``: optional ``[n_mels, 201]`` float32 filterbank (e.g. the array of upstream's
-        ``assets/mel_filters.npz``); default: the Slaney bank computed by ``audio.slaney_mel_filterbank``."""
+        ``assets/mel_filters.npz``); default: the Slaney bank computed by ``audio.slaney_mel_filterbank``.
+        ``n_lanes``: how many engines will share this GPU at the same time (whisper_amd/lanes.py); sizes the grid of the
+        decoder's cross-attention stream (wx_config.n_lanes)."""
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
         if not torch.cuda.is_available():
@@ -54,7 +56,8 @@ class WhisperEngine:
             n_text_layer=dims.n_text_layer, precision=PRECISIONS[precision], max_batch=self.max_batch, device=self.device,
             tok_eot=t.eot, tok_sot=t.sot, tok_translate=t.translate, tok_transcribe=t.transcribe, tok_sot_prev=t.sot_prev,
             tok_sot_lm=t.sot_lm, tok_no_speech=t.no_speech, tok_no_timestamps=t.no_timestamps,
-            tok_timestamp_begin=t.timestamp_begin, tok_blank=t.blank)
+            tok_timestamp_begin=t.timestamp_begin, tok_blank=t.blank, n_lanes=int(n_lanes))
+        self.n_lanes = int(n_lanes)
         handle = ctypes.c_void_p()
         _lib.check(self.lib.wx_create(ctypes.byref(cfg), ctypes.byref(handle)), "wx_create")
         self.handle = handle

@@ -83,10 +83,12 @@ class EngineLanes:
         self._next = 0
 
     @classmethod
-    def create(cls, make_engine: Callable[[], object], n_lanes: int) -> "EngineLanes":
+    def create(cls, make_engine: Callable[[int], object], n_lanes: int) -> "EngineLanes":
+        """``make_engine(n_lanes)`` builds one replica; it should pass ``n_lanes`` on to ``WhisperEngine`` so that the engine
+        sizes its cross-attention grid for its share of the GPU."""
         if n_lanes < 1:
             raise ValueError("n_lanes must be >= 1")
-        return cls([make_engine() for _ in range(n_lanes)])
+        return cls([make_engine(n_lanes) for _ in range(n_lanes)])
 
     @property
     def n_lanes(self) -> int:

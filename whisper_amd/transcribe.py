@@ -59,8 +59,8 @@ def configure(model: str = "base", checkpoint: Optional[str] = None, vocab: Opti
         # upstream derives the non-speech suppress set from the vocabulary it loads (Tokenizer.non_speech_tokens); so do we
         from .engine import default_suppress_ids
         suppress_ids = default_suppress_ids(tokenizer.special, dims.n_vocab, ck.non_speech_tokens_from_vocab(tokenizer.encode))
-    def make():
-        return WhisperEngine(dims, sd, precision=precision, max_batch=max_batch, device=device, suppress_ids=suppress_ids)
+    def make(n_lanes=1):
+        return WhisperEngine(dims, sd, precision=precision, max_batch=max_batch, device=device, suppress_ids=suppress_ids, n_lanes=n_lanes)
     if int(lanes) > 1:
         from .lanes import EngineLanes
         eng = EngineLanes.create(make, int(lanes))
