@@ -301,12 +301,17 @@ def main():
         lanes.submit(back, front(m_front), not args.no_graph, 0, m_back, lane=0).result()
         torch.cuda.synchronize(dev)
         st_ms = [m_front[0].elapsed_time(m_front[1]), m_back[0].elapsed_time(m_back[1]), m_back[1].elapsed_time(m_back[2])]
-        # dominant kernel: event-bracketed eager pass on the same batch, alone on the GPU
+        # dominant kernel: HIP events around every eighth position's launches of it, on the launching stream, in an eager pass of
+        # one batch PER LANE, all lanes at once -- the conditions of the timed region (which replays graphs, where events cannot go)
         prof_ms, prof_n = 0.0, 0
         if not args.no_profile_pass and not args.beam:
-            lanes.submit(back, front(), False, 8, lane=0).result()
+            mels = [front() for _ in range(lanes.n_lanes)]
+            for p in [lanes.submit(back, mels[i], False, 8, lane=i) for i in range(lanes.n_lanes)]:
+                p.result()
             torch.cuda.synchronize(dev)
-            prof_ms, prof_n = eng.last_profile()
+            for e_i in lanes.engines:
+                ms_i, n_i = e_i.last_profile()
+                prof_ms += ms_i; prof_n += n_i
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -356,8 +361,13 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms, "launches_timed": prof_n,
-                "measured": "HIP events around every launch of the kernel in an eager pass of one batch, alone on the GPU (the timed region "
-                            "replays graphs with several batches in flight, where launches of different batches overlap)",
+                "measured": "HIP events around the kernel's launches on their own streams, eager pass of one batch per lane, all lanes at once",
+                "launches_in_flight": lanes.n_lanes, "workgroups_per_launch": B * eng.cross_key_splits if estream else None,
+                "frac_of_share": achieved / (HBM_PEAK_GBS / lanes.n_lanes),      # against 1 / launches_in_flight of the peak
+                "note": ("one workgroup owns a CU; with several batches in flight a launch is sized for its share of the 256 CUs "
+                         "(wx_config.n_lanes) and up to launches_in_flight of them share HBM: frac is per launch against the whole "
+                         "GPU's peak; alone on the GPU at 4 key splits the kernel runs 48 us = 5.1 TB/s = 0.64 "
+                         "(profiles/r02_kernel_stats_bench_lanes1.txt)") if estream and lanes.n_lanes > 1 else None,
             },
         }
         # stage rooflines (SURVEY §8d formulas; encoder FLOPs include the cross-K/V projection)

@@ -196,6 +196,9 @@ int64_t wx_workspace_bytes(wx_engine* e);
  * projections moved to the query side (bf16 engines with max_batch >= 32; same attention, different bf16 rounding points:
  * DESIGN.md section 4).  Fixed at wx_create; the parity tests pick the matching oracle form with it. */
 int32_t wx_cross_attention_form(wx_engine* e);
+/* key splits per row of that cross-attention's stream launch (workgroups per launch = rows x this); fixed at wx_finalize from
+ * max_batch and n_lanes only */
+int32_t wx_cross_key_splits(wx_engine* e);
 
 #ifdef __cplusplus
 }

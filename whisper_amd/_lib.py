@@ -54,6 +54,7 @@ PROTOTYPES = {
     "wx_weight_bytes": (c_i64, [c_vp]),
     "wx_workspace_bytes": (c_i64, [c_vp]),
     "wx_cross_attention_form": (c_i32, [c_vp]),
+    "wx_cross_key_splits": (c_i32, [c_vp]),
 }
 
 _lib = None

@@ -1329,5 +1329,6 @@ int wx_decoder_logits(wx_engine* e, int32_t B, const int32_t* d_tokens, int32_t 
 int64_t wx_weight_bytes(wx_engine* e) { return e ? e->weight_bytes : 0; }
 int64_t wx_workspace_bytes(wx_engine* e) { return e ? e->work_bytes : 0; }
 int32_t wx_cross_attention_form(wx_engine* e) { return e && e->xattn ? 1 : 0; }
+int32_t wx_cross_key_splits(wx_engine* e) { return !e || !e->finalized ? 0 : e->xattn ? e->x_split : cross_attn_key_split(e); }
 
 }  // extern "C"

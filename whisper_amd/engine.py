@@ -109,6 +109,10 @@ class WhisperEngine:
         with max_batch >= 32; include/whisper_amd.h wx_cross_attention_form)."""
         return "encoder_output" if int(self.lib.wx_cross_attention_form(self.handle)) == 1 else "kv"
 
+    @property
+    def cross_key_splits(self) -> int:
+        return int(self.lib.wx_cross_key_splits(self.handle))
+
     # -- audio ingest ---------------------------------------------------------------------------------------
     def pcm16_to_f32(self, pcm16) -> torch.Tensor:
         """int16 PCM (numpy array or tensor) -> float32 samples in [-1, 1) on the device (x / 32768, converted by the
