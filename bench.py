@@ -38,8 +38,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=3)
-    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--steps", type=int, default=8)
+    p.add_argument("--warmup", type=int, default=4)
     p.add_argument("--model", default="large-v3")
     p.add_argument("--batch", type=int, default=64, help="30 s windows per GPU per step")
     p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
