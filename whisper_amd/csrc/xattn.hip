@@ -48,7 +48,7 @@ constexpr int XA_KT = 32;                          // keys per tile (one MFMA k-
 //   C phase   wave w owns the 16-wide column tiles [w D/128, (w+1) D/128) of c: C^T[i][q] += E[key][i]^T . P^T, A operand =
 //             E^T via ds_read_b64_tr_b16 from the image (pitch 2D + 32 bytes: conflict-free), B operand = P from LDS.
 //   Two register sets: the loads of tile t + 2 are issued as soon as tile t's fragments are in the image; the S product of
-//   tile t + 1 shares a phase with the C phase of tile t, the softmax of tile t + 1 with the image write of tile t + 1.
+//   tile t + 1 (matrix pipe) shares a phase with the image write (LDS) and the softmax (2 waves) of tile t.
 // ---------------------------------------------------------------------------------------------------------
 template <int D, int NQT>
 __global__ __launch_bounds__(512) void xattn_estream_kernel(XAttnArgs a) {
@@ -58,7 +58,8 @@ __global__ __launch_bounds__(512) void xattn_estream_kernel(XAttnArgs a) {
     constexpr int KSW = KS_ALL / NSW;                          // k-steps per S wave
     constexpr int ITW = D / 128;                               // 16-wide column tiles of c per wave
     __shared__ __attribute__((aligned(16))) char img[XA_KT * PITCH];
-    __shared__ __attribute__((aligned(16))) f32x4 sbuf[NSW * NQT * 2 * 64];        // [S wave][query tile][key half][lane]
+    constexpr int SB = NSW * NQT * 2 * 64;
+    __shared__ __attribute__((aligned(16))) f32x4 sbuf[2 * SB];                    // 2 x [S wave][query tile][key half][lane]
     __shared__ __attribute__((aligned(16))) bf16x8 pbuf[NQT * 64];
     __shared__ float abuf[NQT * 16], lbuf[NQT * 16];
     const int row = blockIdx.x / a.n_split, split = blockIdx.x % a.n_split;
@@ -111,24 +112,32 @@ __global__ __launch_bounds__(512) void xattn_estream_kernel(XAttnArgs a) {
     load_tile(stB, t0 + 1);
     __builtin_amdgcn_sched_barrier(0);
     // S product of one tile, from the registers its loads landed in, to the partial-score buffer
-    auto s_phase = [&](bf16x8 (&st)[2][KSW]) {
+    auto s_phase = [&](bf16x8 (&st)[2][KSW], int sb) {
 #if !(XA_SKIP & 1)
         if (s_role) {
+            // the NQT x 2 accumulation chains advance together: consecutive MFMAs are independent
+            f32x4 acc[NQT][2];
 #pragma unroll
             for (int qt = 0; qt < NQT; ++qt)
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int hh = 0; hh < 2; ++hh) acc[qt][hh] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int ks = 0; ks < KSW; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st[hh][ks], qf[qt][ks], acc, 0, 0, 0);
-                    sbuf[((wid * NQT + qt) * 2 + hh) * 64 + lane] = acc;
-                }
+            for (int ks = 0; ks < KSW; ++ks)
+#pragma unroll
+                for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh)
+                        acc[qt][hh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st[hh][ks], qf[qt][ks], acc[qt][hh], 0, 0, 0);
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) sbuf[sb * SB + ((wid * NQT + qt) * 2 + hh) * 64 + lane] = acc[qt][hh];
         }
 #endif
     };
-    // phase A of tile t: its fragments -> the image (then its registers take the loads of tile t + 2), while wave qt < NQT runs
-    // the online softmax of query tile qt on the partial scores the previous phase B left
-    auto phase_a = [&](bf16x8 (&st)[2][KSW], int t) {
+    // phase A of tile t: its fragments -> the image (then its registers take the loads of tile t + 2), wave qt < NQT runs the online
+    // softmax of query tile qt on the score tiles of buffer sb, and every wave the S product of tile t + 1 into buffer sb ^ 1
+    auto phase_a = [&](bf16x8 (&st)[2][KSW], bf16x8 (&stn)[2][KSW], int t, int sb) {
 #if !(XA_SKIP & 16)
         if (s_role) {
 #pragma unroll
@@ -145,8 +154,8 @@ __global__ __launch_bounds__(512) void xattn_estream_kernel(XAttnArgs a) {
             f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
 #pragma unroll
             for (int w = 0; w < NSW; ++w) {                     // fixed order: the K slices in ascending order
-                s0 += sbuf[((w * NQT + wid) * 2 + 0) * 64 + lane];
-                s1 += sbuf[((w * NQT + wid) * 2 + 1) * 64 + lane];
+                s0 += sbuf[sb * SB + ((w * NQT + wid) * 2 + 0) * 64 + lane];
+                s1 += sbuf[sb * SB + ((w * NQT + wid) * 2 + 1) * 64 + lane];
             }
             if ((t + 1) * XA_KT > T) {                          // only the last tile of the window can run past the keys
 #pragma unroll
@@ -176,6 +185,7 @@ __global__ __launch_bounds__(512) void xattn_estream_kernel(XAttnArgs a) {
             if (g == 0) abuf[wid * 16 + r] = alpha;
         }
 #endif
+        s_phase(stn, sb ^ 1);       // scores of tile t + 1 from the other register set (its loads have had a whole tile to land)
     };
     // C phase of the tile in the image: lane (g, r) receives E[key = 16hh + 4g + j][i = 16 itile + r]
     auto c_phase = [&]() {
@@ -214,26 +224,26 @@ __global__ __launch_bounds__(512) void xattn_estream_kernel(XAttnArgs a) {
         }
 #endif
     };
-    // Two barriers per tile.  Phase A(t): image write of tile t || softmax of tile t (scores from phase B(t - 1)).
-    // Phase B(t): C phase of tile t (image + P), then the S product of tile t + 1 from the other register set (its loads have had
-    // a whole tile to land).  Past the last tile the loads return zeros and the S product is idle work that nobody reads.
-    s_phase(stA);
+    // Two barriers per tile.  Phase A(t): image write of tile t (LDS), the S product of tile t + 1 from the other register set
+    // (matrix pipe; its score tiles go to the other half of the double-buffered score buffer) and, on NQT waves, the softmax of
+    // tile t on the scores the previous phase A left.  Phase B(t): the C product of tile t (image + P).  Past the last tile the
+    // loads return zeros and the S product is idle work that nobody reads.  (The softmax beside the C product instead, with P
+    // double-buffered: 121 instead of 106 us at one key split.)
+    s_phase(stA, 0);
     __syncthreads();
     int t = t0;
     for (; t + 1 < t1; t += 2) {        // straight-line body: every path through the loop issues the same loads, the wait counts stay exact
-        phase_a(stA, t);
+        phase_a(stA, stB, t, 0);
         __syncthreads();
         c_phase();
-        s_phase(stB);
         __syncthreads();
-        phase_a(stB, t + 1);
+        phase_a(stB, stA, t + 1, 1);
         __syncthreads();
         c_phase();
-        s_phase(stA);
         __syncthreads();
     }
     if (t < t1) {
-        phase_a(stA, t);
+        phase_a(stA, stB, t, 0);
         __syncthreads();
         c_phase();
     }
