@@ -17,6 +17,20 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 enum DType : int { DT_F32 = 0, DT_BF16 = 1 };
 static inline size_t dtype_size(int dt) { return dt == DT_F32 ? 4 : 2; }
 
+// GELU.  fp32 outputs (token-exact engines): the library erf.  bf16 outputs: erf from Abramowitz & Stegun 7.1.26 (|error| <=
+// 1.5e-7, far below a bf16 output's rounding step): one exp2, one rcp and six fma instead of the library's two-branch polynomial
+// -- the MLP up projection applies it to 5120 values per row.  Every bf16 kernel uses the same form, so a row's result does not
+// depend on which GEMM kernel its batch size selects.
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f); p = fmaf(p, t, -0.284496736f); p = fmaf(p, t, 0.254829592f);
+    const float erfc_z = p * t * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);        // 1 - erf(z), z >= 0
+    return 0.5f * x * (1.0f + copysignf(1.0f - erfc_z, x));
+}
+
 constexpr int HEAD_DIM = 64;      // every Whisper size uses 64-wide heads
 constexpr int KV_PAGE = 16;       // tokens per page of the decoder self-attention KV cache
 constexpr int N_FFT = 400;

@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void reduce_bias_gelu_kernel(const float* __re
     v += *reinterpret_cast<const f32x4*>(bias + (i * 4) % N);
     bf16x4 o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = (bf16)(0.5f * v[j] * (1.0f + erff(v[j] * 0.70710678118654752440f)));
+    for (int j = 0; j < 4; ++j) o[j] = (bf16)gelu_erf_fast(v[j]);
     reinterpret_cast<bf16x4*>(out)[i] = o;
 }
 

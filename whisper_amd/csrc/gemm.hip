@@ -14,8 +14,6 @@
 
 namespace wx {
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-
 // The epilogue of 4 consecutive columns n..n+3 of row m is split in two so that a kernel can issue ALL of a tile's
 // residual / positional loads before the first store: the residual stream is updated in place (out == residual), so
 // the compiler must keep every load behind every earlier store, and a fused load-add-store per fragment degenerates
@@ -41,7 +39,7 @@ __device__ __forceinline__ void epilogue_finish4(const GemmEpilogue& e, int m, i
     }
     if (e.act == 1) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+        for (int j = 0; j < 4; ++j) v[j] = e.out_dtype == DT_BF16 ? gelu_erf_fast(v[j]) : gelu_erf(v[j]);
     }
     v += add;
     int64_t off;
@@ -70,6 +68,62 @@ __device__ __forceinline__ void epilogue_finish4(const GemmEpilogue& e, int m, i
 
 __device__ __forceinline__ void epilogue_store4(const GemmEpilogue& e, int m, int n, f32x4 v, int M, int N) {
     epilogue_finish4(e, m, n, v, epilogue_load4(e, m, n, M, N), M, N);
+}
+
+// The same epilogue for a lane that keeps ONE group of 4 columns and walks down rows (the 256x256 kernel's slab read-back: row
+// m, m + step, ...).  Everything that depends on the column only -- bias, column scale, split / head / channel of the head-split
+// layout -- is worked out once, and the row's (batch, position) pair advances by addition instead of two integer divisions per
+// element group: the generic form above costs ~250 VALU instructions per group, 15 us of a 49-us tile.
+struct EpiColumn {
+    f32x4 bias; float scale; char* base; int64_t col_off; bool live;
+    int b, t;                      // (m / period, m % period) of the current row: hs_T (mode 1) or out_rows_per_batch (mode 0 remap)
+    int period;
+};
+__device__ __forceinline__ EpiColumn epi_column(const GemmEpilogue& e, int m, int n, int N) {
+    EpiColumn c;
+    c.live = n < N;
+    const int nn = c.live ? n : 0;
+    c.bias = e.bias ? *reinterpret_cast<const f32x4*>(e.bias + nn) : f32x4{0.f, 0.f, 0.f, 0.f};
+    c.scale = e.colscale_period ? e.colscale[nn / e.colscale_period] : 1.0f;
+    const int es = e.out_dtype == DT_F32 ? 4 : 2;
+    if (e.mode == 0) {
+        c.base = reinterpret_cast<char*>(e.out); c.col_off = (int64_t)nn * es;
+        c.period = e.out_rows_per_batch;
+    } else {
+        const int s = nn / e.hs_d, rem = nn % e.hs_d;
+        c.base = reinterpret_cast<char*>(e.out_split[s]);
+        c.col_off = ((int64_t)(rem / HEAD_DIM) * e.hs_T * HEAD_DIM + rem % HEAD_DIM) * es;
+        c.period = e.hs_T;
+    }
+    c.b = c.period ? m / c.period : 0; c.t = c.period ? m % c.period : m;
+    return c;
+}
+__device__ __forceinline__ void epi_advance(EpiColumn& c, int step) {       // step < period
+    c.t += step;
+    if (c.period && c.t >= c.period) { c.t -= c.period; ++c.b; }
+}
+__device__ __forceinline__ void epi_finish_row(const GemmEpilogue& e, const EpiColumn& c, bool row_ok, f32x4 v, const EpiAddend& add) {
+    if (!row_ok || !c.live) return;
+    v += c.bias;
+    v *= c.scale;
+    if (e.act == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = e.out_dtype == DT_BF16 ? gelu_erf_fast(v[j]) : gelu_erf(v[j]);
+    }
+    v += add;
+    int64_t row;
+    if (e.mode == 0) row = c.period ? (int64_t)c.b * e.out_batch_rows + e.out_row_offset + c.t : (int64_t)c.t;
+    else row = ((int64_t)c.b * e.hs_H) * e.hs_T + c.t;
+    if (e.out_dtype == DT_F32) {
+        const int64_t ld = e.mode == 0 ? e.ldo : HEAD_DIM;
+        *reinterpret_cast<f32x4*>(c.base + row * ld * 4 + c.col_off) = v;
+    } else {
+        const int64_t ld = e.mode == 0 ? e.ldo : HEAD_DIM;
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
+        *reinterpret_cast<bf16x4*>(c.base + row * ld * 2 + c.col_off) = o;
+    }
 }
 
 __device__ __forceinline__ int64_t a_row_offset(const GemmArgs& g, int m) {
@@ -318,19 +372,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_tile256_kernel(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 *reinterpret_cast<f32x4*>(slab + (i * 16 + r) * TL_SLAB_ROW + (j * 16 + gq * 4) * 4) = acc[j][p * 4 + i];
+        const int mrow = m0 + wm * 128 + p * 64 + (lane >> 4), ncol = n0 + wn * 64 + (lane & 15) * 4;
+        EpiColumn col = epi_column(g.ep, mrow, ncol, g.N);
         if (g.ep.residual || g.ep.rowadd) {
             // in-place residual update: every load of the pass is issued before its first store (see epilogue_load4)
             EpiAddend add[16];
 #pragma unroll
             for (int it = 0; it < 16; ++it)
-                add[it] = epilogue_load4(g.ep, m0 + wm * 128 + p * 64 + it * 4 + (lane >> 4), n0 + wn * 64 + (lane & 15) * 4, g.M, g.N);
+                add[it] = epilogue_load4(g.ep, mrow + it * 4, ncol, g.M, g.N);
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
                 const int row = it * 4 + (lane >> 4), c = lane & 15;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * TL_SLAB_ROW + c * 16);
-                epilogue_finish4(g.ep, m0 + wm * 128 + p * 64 + row, n0 + wn * 64 + c * 4, v, add[it], g.M, g.N);
+                epi_finish_row(g.ep, col, mrow + it * 4 < g.M, v, add[it]);
+                epi_advance(col, 4);
             }
         } else {
             __builtin_amdgcn_wave_barrier();
@@ -339,7 +396,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_tile256_kernel(GemmArgs g) {
             for (int it = 0; it < 16; ++it) {
                 const int row = it * 4 + (lane >> 4), c = lane & 15;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * TL_SLAB_ROW + c * 16);
-                epilogue_finish4(g.ep, m0 + wm * 128 + p * 64 + row, n0 + wn * 64 + c * 4, v, f32x4{0.f, 0.f, 0.f, 0.f}, g.M, g.N);
+                epi_finish_row(g.ep, col, mrow + it * 4 < g.M, v, f32x4{0.f, 0.f, 0.f, 0.f});
+                epi_advance(col, 4);
             }
         }
         __builtin_amdgcn_wave_barrier();
