@@ -389,6 +389,34 @@ __global__ __launch_bounds__(512) void gemm_bf16_tile256_kernel(GemmArgs g) {
                 epi_finish_row(g.ep, col, mrow + it * 4 < g.M, v, add[it]);
                 epi_advance(col, 4);
             }
+        } else if (g.ep.out_dtype == DT_BF16 && n0 + 256 <= g.N) {
+            // bf16 output: 8 columns = one 16-B store per lane, 8 rows per wave instruction (two column groups of one EpiColumn)
+            const int mrow8 = m0 + wm * 128 + p * 64 + (lane >> 3), ncol8 = n0 + wn * 64 + (lane & 7) * 8;
+            EpiColumn c8 = epi_column(g.ep, mrow8, ncol8, g.N);
+            const f32x4 bias_hi = g.ep.bias ? *reinterpret_cast<const f32x4*>(g.ep.bias + ncol8 + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 4
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 8 + (lane >> 3), c = lane & 7;
+                f32x4 v0 = *reinterpret_cast<const f32x4*>(slab + row * TL_SLAB_ROW + c * 32);
+                f32x4 v1 = *reinterpret_cast<const f32x4*>(slab + row * TL_SLAB_ROW + c * 32 + 16);
+                if (mrow8 + it * 8 < g.M) {
+                    v0 = (v0 + c8.bias) * c8.scale; v1 = (v1 + bias_hi) * c8.scale;
+                    if (g.ep.act == 1) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { v0[j] = gelu_erf_fast(v0[j]); v1[j] = gelu_erf_fast(v1[j]); }
+                    }
+                    const int64_t orow = g.ep.mode == 0 ? (c8.period ? (int64_t)c8.b * g.ep.out_batch_rows + g.ep.out_row_offset + c8.t : (int64_t)c8.t)
+                                                        : ((int64_t)c8.b * g.ep.hs_H) * g.ep.hs_T + c8.t;
+                    const int64_t ld = g.ep.mode == 0 ? g.ep.ldo : HEAD_DIM;
+                    bf16x8 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { o[j] = (bf16)v0[j]; o[4 + j] = (bf16)v1[j]; }
+                    *reinterpret_cast<bf16x8*>(c8.base + orow * ld * 2 + c8.col_off) = o;
+                }
+                epi_advance(c8, 8);
+            }
         } else {
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
