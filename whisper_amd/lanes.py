@@ -4,8 +4,9 @@ Why.  One batch of 30 s windows keeps the GPU busy only in patches: the decode l
 dozen per decoder layer and token, 4-12 us each, most of them waiting on one memory round trip) around one bandwidth-bound
 stream per layer, and the encoder runs alone in front of it.  A second, independent batch fills the holes -- its short launches
 run beside the other batch's stream, its encoder beside the other's decode loop.  Measured on one MI355X, large-v3 bf16, 64
-windows per batch, 224 tokens: 1053 ms per batch with 1 lane, 851 with 2, 807 with 3, 781 with 4 (1823 -> 2459 audio-s/s), no
-further gain at 6 or 8 (the runtime maps streams onto 4 hardware queues).  The batches
+windows per batch, 224 tokens: 1053 ms per batch with 1 lane, 816 with 2, 742 with 3, 705 with 4 (1823 -> 2723 audio-s/s; each
+engine sizes its cross-attention grid for its share of the GPU, wx_config.n_lanes), no further gain at 6 or 8 (the runtime maps
+streams onto 4 hardware queues).  The batches
 stay what they were (same kernels, same max_batch, same key split), so a window's ids do not depend on the lane it ran on
 (tests/test_gpu_api.py::test_lanes_decode_the_same_ids).
 
