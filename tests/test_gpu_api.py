@@ -506,3 +506,23 @@ def test_lanes_decode_the_same_ids():
         assert isinstance(seq["text"], str)
     finally:
         tx.close()
+
+
+def test_nan_input_ends_rows_instead_of_indexing_with_garbage():
+    """Audio that turns into NaN features (a NaN sample) makes every logit NaN: no candidate ever beats the initial one, whose
+    id indexes nothing.  The sampler ends such a row with EOT (and the embedding lookup clamps any id it is handed), so the
+    call returns -- empty transcripts -- instead of reading outside the token table."""
+    from whisper_amd.engine import WhisperEngine
+    dims = ck.dims_for("micro")
+    eng = WhisperEngine(dims, ck.synthetic_state_dict(dims, seed=0), precision="bf16", max_batch=2)
+    try:
+        mel = torch.full((2, dims.n_mels, 3000), float("nan"), device="cuda")
+        eng.encode_windows(mel)
+        assert torch.isnan(eng.encoder_output(2)).all()
+        init = eng.initial_tokens(0)
+        r = eng.decode_greedy(2, init, max_new_tokens=6)
+        t = r["tokens"].cpu()
+        assert (t[:, len(init):] == eng.tok.eot).all() and (r["n_tokens"].cpu() == 0).all()
+        assert int(t.max()) < dims.n_vocab and int(t.min()) >= 0
+    finally:
+        eng.close()

@@ -106,8 +106,10 @@ int launch_reduce_layernorm(float* x, const float* partial, int n_split, const f
 int launch_reduce_bias_gelu(const float* partial, int n_split, const float* bias, void* out_bf16, int rows, int N, hipStream_t st);
 // x[b][:] = tok_emb[tokens[b*ld_tok + *d_pos]][:] + pos_emb[*d_pos][:]   (fp32 out; embedding tables in `dt`)
 // group > 1 (prompt pass): row r embeds position *d_pos + r % group of sequence r / group (rows = sequences x group)
+// n_tok / n_pos: rows of the two tables; an id or position outside them is clamped (a row of NaN logits ends with EOT in the
+// sampler, but nothing that reads a table trusts an id it did not check)
 int launch_embed(const void* tok_emb, const void* pos_emb, int dt, const int32_t* tokens, int ld_tok,
-                 const int32_t* d_pos, float* x, int B, int d, hipStream_t st, int group = 1);
+                 const int32_t* d_pos, float* x, int B, int d, hipStream_t st, int group, int n_tok, int n_pos);
 int launch_convert_f32(const float* in, void* out, int out_dtype, int64_t n, hipStream_t st);
 int launch_to_f32(const void* in, int in_dtype, float* out, int64_t n, hipStream_t st);
 // mel (w, m, t) -> conv input xpad[w][1 + t][c_pad] (dtype dt); zero rows 0 and T+1, zero channels >= n_mels,

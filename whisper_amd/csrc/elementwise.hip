@@ -303,19 +303,20 @@ int launch_reduce_bias_gelu(const float* partial, int n_split, const float* bias
 // ---------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void embed_kernel(const T* __restrict__ tok_emb, const T* __restrict__ pos_emb, const int32_t* __restrict__ tokens,
-                             int ld_tok, const int32_t* __restrict__ d_pos, float* __restrict__ x, int d, int group) {
-    const int r = blockIdx.x, b = r / group, t = *d_pos + r % group;
-    const int token = tokens[b * ld_tok + t];
+                             int ld_tok, const int32_t* __restrict__ d_pos, float* __restrict__ x, int d, int group, int n_tok, int n_pos) {
+    const int r = blockIdx.x, b = r / group;
+    int t = *d_pos + r % group; if (t > n_pos - 1) t = n_pos - 1; if (t < 0) t = 0;          // ids index two tables: never outside them
+    int token = tokens[b * ld_tok + t]; if ((unsigned)token >= (unsigned)n_tok) token = n_tok - 1;
     const T* te = tok_emb + (int64_t)token * d;
     const T* pe = pos_emb + (int64_t)t * d;
     for (int i = threadIdx.x; i < d; i += blockDim.x) x[(int64_t)r * d + i] = (float)te[i] + (float)pe[i];
 }
 
 int launch_embed(const void* tok_emb, const void* pos_emb, int dt, const int32_t* tokens, int ld_tok, const int32_t* d_pos,
-                 float* x, int B, int d, hipStream_t st, int group) {
-    if (group < 1) return -1;
-    if (dt == DT_F32) hipLaunchKernelGGL(embed_kernel<float>, dim3(B), dim3(256), 0, st, (const float*)tok_emb, (const float*)pos_emb, tokens, ld_tok, d_pos, x, d, group);
-    else hipLaunchKernelGGL(embed_kernel<bf16>, dim3(B), dim3(256), 0, st, (const bf16*)tok_emb, (const bf16*)pos_emb, tokens, ld_tok, d_pos, x, d, group);
+                 float* x, int B, int d, hipStream_t st, int group, int n_tok, int n_pos) {
+    if (group < 1 || n_tok < 1 || n_pos < 1) return -1;
+    if (dt == DT_F32) hipLaunchKernelGGL(embed_kernel<float>, dim3(B), dim3(256), 0, st, (const float*)tok_emb, (const float*)pos_emb, tokens, ld_tok, d_pos, x, d, group, n_tok, n_pos);
+    else hipLaunchKernelGGL(embed_kernel<bf16>, dim3(B), dim3(256), 0, st, (const bf16*)tok_emb, (const bf16*)pos_emb, tokens, ld_tok, d_pos, x, d, group, n_tok, n_pos);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -475,6 +476,9 @@ __device__ __forceinline__ void sampler_commit(const SamplerArgs& s, int b, int 
         const float ts_lp = lse_ts - lse_all, text_lp = max_text - lse_all;
         if (ts_lp > text_lp) { chosen = best_ts.i; logprob = best_ts.raw - lse_ts; }   // only timestamps remain
     }
+    // a row whose logits are all NaN (NaN weights or audio) has no best candidate: it ends here instead of carrying an id that
+    // indexes nothing
+    if ((unsigned)chosen >= (unsigned)s.n_vocab) { chosen = s.tok_eot; logprob = 0.f; }
     const bool alive = prev_id != s.tok_eot;
     if (alive) s.sum_logprob[b] = prev_sum + logprob;
     const int next = alive ? chosen : s.tok_eot;

@@ -804,7 +804,7 @@ static int decode_step_f32(wx_engine* e, int B, const SamplerArgs* sa, hipStream
     const int d = e->d, dtp = e->dt, T = e->T;
     const size_t es = dtype_size(dtp);
     const wx_config& c = e->cfg;
-    WX_TRY(launch_embed(e->tok_emb, e->dec_pos, dtp, e->tokens, e->ld_tok, e->d_pos, e->dx, B, d, st));
+    WX_TRY(launch_embed(e->tok_emb, e->dec_pos, dtp, e->tokens, e->ld_tok, e->d_pos, e->dx, B, d, st, 1, e->cfg.n_vocab, e->cfg.n_text_ctx));
     const size_t cross_layer = (size_t)c.max_batch * e->Ht * T * HEAD_DIM;
     const size_t self_layer = (size_t)c.max_batch * e->n_pages_seq * e->Ht * KV_PAGE * HEAD_DIM;
     const int n_split = cross_attn_key_split(e);
@@ -893,7 +893,7 @@ static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, floa
     char* datt = (char*)e->datt + (size_t)b0 * d * es;
     char* dhid = (char*)e->dhid + (size_t)b0 * 4 * d * es;
     if (G < 1 || B % G || (G > 1 && (e->beam_n > 0 || b0 != 0))) return fail(WX_ERR_INVALID, "bad prompt-pass grouping");
-    WX_TRY(launch_embed(e->tok_emb, e->dec_pos, dtp, e->tokens + (size_t)b0 * e->ld_tok, e->ld_tok, e->d_pos, dx, B, d, st, G));
+    WX_TRY(launch_embed(e->tok_emb, e->dec_pos, dtp, e->tokens + (size_t)b0 * e->ld_tok, e->ld_tok, e->d_pos, dx, B, d, st, G, c.n_vocab, c.n_text_ctx));
     const size_t cross_layer = (size_t)c.max_batch * e->Ht * T * HEAD_DIM, cross_b0 = (size_t)b0 * e->Ht * T * HEAD_DIM;
     const size_t self_layer = (size_t)c.max_batch * e->n_pages_seq * e->Ht * KV_PAGE * HEAD_DIM;
     const int n_split = cross_attn_key_split(e);
