@@ -50,7 +50,7 @@ typedef struct {
     int32_t tok_no_speech, tok_no_timestamps, tok_timestamp_begin, tok_blank;
     int32_t n_lanes;        /* engines that will share this GPU at the same time (whisper_amd/lanes.py keeps several batches in flight);
                                0 or 1 = this engine has the GPU to itself.  Sizes the grid of the decoder's cross-attention stream
-                               (key splits per row = ceil(256 CUs / (n_lanes x rows per pass)), at most 8): a launch that fills every CU
+                               (key splits per row = 256 CUs / (n_lanes x rows per pass), rounded down alone and up when sharing, 1 to 8): a launch that fills every CU
                                finishes one batch sooner, one that leaves CUs to the other lanes finishes all of them sooner.  A
                                property of the engine like max_batch: results do not depend on the batch at hand. */
 } wx_config;

@@ -526,3 +526,21 @@ def test_nan_input_ends_rows_instead_of_indexing_with_garbage():
         assert int(t.max()) < dims.n_vocab and int(t.min()) >= 0
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("max_batch,n_lanes,splits,form", [(64, 1, 4, "encoder_output"), (48, 1, 5, "encoder_output"), (80, 1, 3, "encoder_output"),
+                                                            (32, 1, 8, "encoder_output"), (64, 4, 1, "encoder_output"), (64, 3, 2, "encoder_output"),
+                                                            (64, 2, 2, "encoder_output"), (128, 1, 4, "encoder_output"), (16, 1, None, "kv")])
+def test_cross_attention_grid_is_a_function_of_max_batch_and_lanes(max_batch, n_lanes, splits, form):
+    """wx_cross_attention_form / wx_cross_key_splits: the form and the key split of the decoder's cross-attention are fixed at
+    engine creation from max_batch and n_lanes alone (batch invariance), one round of workgroups when the engine has the GPU to
+    itself (128 rows run as two passes of 64)."""
+    from whisper_amd.engine import WhisperEngine
+    dims = ck.dims_for("micro")
+    eng = WhisperEngine(dims, ck.synthetic_state_dict(dims, seed=0), precision="bf16", max_batch=max_batch, n_lanes=n_lanes)
+    try:
+        assert eng.cross_form == form
+        if splits is not None:
+            assert eng.cross_key_splits == splits
+    finally:
+        eng.close()

@@ -526,8 +526,10 @@ int wx_finalize(wx_engine* e) {
         // 2652 / 2723 RTFx at 4 / 3 / 2 / 1 splits -- the stream kernel owns its CU's registers, so a launch that fills the chip
         // stalls every other lane's short launches for its whole duration)
         {
+            // alone on the GPU: rounded DOWN, one full round of workgroups (48 rows: 5 splits = 240 workgroups, not 6 = 288 in two
+            // rounds); sharing it: rounded up (3 lanes x 64 rows: 2 splits 2587 RTFx, 1 split 2473)
             const int share = (c.n_lanes > 1 ? c.n_lanes : 1) * e->pass_rows;
-            e->x_split = (256 + share - 1) / share;
+            e->x_split = c.n_lanes > 1 ? (256 + share - 1) / share : 256 / share;
         }
         if (e->x_split < 1) e->x_split = 1; if (e->x_split > 8) e->x_split = 8;
         if (const char* xs = getenv("WX_XATTN_SPLIT")) { const int v = atoi(xs); if (v >= 1 && v <= 8) e->x_split = v; }
