@@ -226,13 +226,21 @@ class OracleWhisper:
     the two emulations MEASURES that noise floor, and the GPU tests bound the device's distance by a small multiple of it."""
 
     def __init__(self, dims, sd: Dict[str, torch.Tensor], emulate_bf16: bool = False, acc_dtype: torch.dtype = torch.float32,
-                 cross_form: str = "encoder_output"):
+                 cross_form: str = "encoder_output", cross_key_splits: Optional[int] = None, flash_tiles: bool = False):
         """``cross_form`` (bf16 emulation only): "encoder_output" = the engine's cross-attention on E itself (bf16 engines with
-        max_batch >= 32), "kv" = on cached K/V (smaller engines, beam search); WhisperEngine.cross_form says which one runs."""
+        max_batch >= 32), "kv" = on cached K/V (smaller engines, beam search); WhisperEngine.cross_form says which one runs.
+        ``cross_key_splits`` (encoder_output form): also restate the stream kernel's ONLINE softmax -- tiles of 32 keys, the
+        softmax weights rounded to bf16 against the RUNNING maximum of their key split, each split's context normalised by its
+        own sum and rounded to bf16, the splits combined in fp32 and rounded again (WhisperEngine.cross_key_splits says how
+        many) -- instead of rounding the weights once against the final maximum.  ``flash_tiles``: the same for the ENCODER's
+        flash-attention kernel (whisper_amd/csrc/flash.hip: tiles of 64 keys, weights rounded to bf16 against the running
+        maximum, row sum of the unrounded weights)."""
         assert cross_form in ("encoder_output", "kv")
         self.dims = dims
         self.bf16 = bool(emulate_bf16)
         self.absorbed = self.bf16 and cross_form == "encoder_output"
+        self.cross_key_splits = int(cross_key_splits) if cross_key_splits else None
+        self.flash_tiles = bool(flash_tiles) and self.bf16
         self.dt = acc_dtype
         self.sd = {k: v.to(acc_dtype) for k, v in sd.items()}
         if self.bf16:
@@ -257,7 +265,9 @@ class OracleWhisper:
         qk = q @ k.transpose(-1, -2)
         if mask is not None:
             qk = qk + mask
-        if self.bf16 and round_p:
+        if self.bf16 and round_p and self.flash_tiles:
+            out = self._online_attention(qk, v, 64)
+        elif self.bf16 and round_p:
             p = torch.exp(qk - qk.amax(dim=-1, keepdim=True))
             out = (self._r(p) @ v) / p.sum(dim=-1, keepdim=True)
         else:
@@ -275,11 +285,62 @@ class OracleWhisper:
         wk = sd[p + ".key.weight"].view(n_head, hd, D)                   # Wk_h: rows h*64 .. of the key projection
         qt = self._r(torch.einsum("bthc,hcd->bhtd", q, wk) * s)          # q~ [B, H, t, D]
         sc = qt @ xa.transpose(-1, -2)[:, None]                          # [B, H, t, 1500]
-        pr = torch.exp(sc - sc.amax(dim=-1, keepdim=True))
-        ctx = self._r((self._r(pr) @ xa[:, None]) / pr.sum(dim=-1, keepdim=True))     # [B, H, t, D]
+        if self.cross_key_splits:
+            ctx = self._online_context(sc, xa, self.cross_key_splits)
+        else:
+            pr = torch.exp(sc - sc.amax(dim=-1, keepdim=True))
+            ctx = self._r((self._r(pr) @ xa[:, None]) / pr.sum(dim=-1, keepdim=True))     # [B, H, t, D]
         wv = sd[p + ".value.weight"].view(n_head, hd, D)
         out = torch.einsum("bhtd,hcd->bthc", ctx, wv).reshape(B, t, D) + sd[p + ".value.bias"]
         return self._r(out)
+
+    def _online_attention(self, qk, v, tile):
+        """softmax(qk) v the way a flash kernel with `tile` keys per step evaluates it: weights exp(score - running maximum)
+        rounded to bf16 for the P.V product, unrounded in the row sum, earlier tiles rescaled in fp32 (flash.hip)."""
+        *lead, T = qk.shape
+        n_t = (T + tile - 1) // tile
+        pad = n_t * tile - T
+        s_p = torch.cat([qk, torch.full((*lead, pad), float("-inf"), dtype=qk.dtype)], dim=-1) if pad else qk
+        s_t = s_p.view(*lead, n_t, tile)
+        m_run = torch.cummax(s_t.amax(dim=-1), dim=-1).values
+        p = torch.exp(s_t - m_run[..., None])
+        resc = torch.exp(m_run - m_run[..., -1:])
+        l = (p.sum(dim=-1) * resc).sum(dim=-1)
+        pe = (self._r(p) * resc[..., None]).reshape(*lead, n_t * tile)[..., :T]
+        return (pe @ v) / l[..., None]
+
+    def _online_context(self, sc, xa, n_split, tile=32):
+        """The stream kernel's softmax-weighted context, rounding point for rounding point (whisper_amd/csrc/xattn.hip,
+        xattn_estream_kernel + the combine of xattn_cproj_kernel): key split s takes the 32-key tiles [s nt / S, (s+1) nt / S)
+        of the nt = ceil(T / 32) tiles (T padded to a multiple of 32: zero rows, scores -inf); per tile the weights are
+        exp(score - running maximum), rounded to bf16 for the P.E product and left unrounded in the row sum, earlier tiles
+        rescaled by exp(old maximum - new maximum) in fp32; the split's context is divided by its own sum and rounded to
+        bf16; the splits are combined with w_s = l_s exp(m_s - M) / sum in fp32 and the result rounded to bf16."""
+        B, H, t, T = sc.shape
+        nt = (((T + 15) // 16 + 1) // 2 * 2) // 2                          # the engine's x_nt16 / 2
+        parts, ms, ls = [], [], []
+        for s_i in range(n_split):
+            t0, t1 = s_i * nt // n_split, (s_i + 1) * nt // n_split
+            k0, k1 = t0 * tile, min(t1 * tile, T)
+            s_sp = sc[..., k0:k1]
+            n_t = t1 - t0
+            pad = n_t * tile - (k1 - k0)
+            if pad:
+                s_sp = torch.cat([s_sp, torch.full((B, H, t, pad), float("-inf"), dtype=sc.dtype)], dim=-1)
+            s_t = s_sp.view(B, H, t, n_t, tile)
+            m_run = torch.cummax(s_t.amax(dim=-1), dim=-1).values          # [B, H, t, n_t] running maximum after each tile
+            m_fin = m_run[..., -1:]
+            p = torch.exp(s_t - m_run[..., None])                          # weights against the running maximum of their tile
+            resc = torch.exp(m_run - m_fin)                                # product of the later tiles' rescale factors
+            l = (p.sum(dim=-1) * resc).sum(dim=-1)                         # row sum: unrounded weights
+            pe = (self._r(p) * resc[..., None]).reshape(B, H, t, n_t * tile)[..., :k1 - k0]
+            c = pe @ xa[:, None, k0:k1]
+            parts.append(self._r(c / l[..., None]).to(self.dt)); ms.append(m_fin[..., 0]); ls.append(l)
+        m_all = torch.stack(ms, dim=-1)
+        w = torch.stack(ls, dim=-1) * torch.exp(m_all - m_all.amax(dim=-1, keepdim=True))
+        w = w / w.sum(dim=-1, keepdim=True)
+        ctx = sum(w[..., i, None] * parts[i] for i in range(n_split))
+        return self._r(ctx)
 
     def _lin(self, x, prefix, bias=True):
         return F.linear(x, self.sd[prefix + ".weight"], self.sd[prefix + ".bias"] if bias else None)

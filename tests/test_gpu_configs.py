@@ -21,7 +21,8 @@ from whisper_amd.audio import synthetic_audio
 
 pytestmark = pytest.mark.gpu
 
-BF16_NOISE_FACTOR = 2.0   # ||hip - emulation|| <= this x ||emulation(fp64 acc) - emulation(fp32 acc)||, encoder output and logits
+BF16_NOISE_FACTOR = 1.5   # ||hip - emulation|| <= this x ||emulation(fp64 acc) - emulation(fp32 acc)||, encoder output and logits
+                          # (measured 0.98-1.08 at these sizes; the emulation restates the kernels' online softmax, tests/test_gpu_parity.py)
 
 
 def rms_err(a, b):
@@ -30,15 +31,17 @@ def rms_err(a, b):
 
 
 _SD = {}
+_EMU = {}      # emulation results per (weights key, probe windows): they do not depend on the engine's launch configuration
 
 
-def weights(name):
-    """the benchmark's weights: synthetic_state_dict(dims, seed=0) with its defaults (bench.py)"""
-    if name not in _SD:
+def weights(name, **kw):
+    """the benchmark's weights: synthetic_state_dict(dims, seed=0) with its defaults (bench.py), or with the given overrides"""
+    key = (name, tuple(sorted(kw.items())))
+    if key not in _SD:
         _SD.clear()                      # one 6 GB state dict at a time
         dims = ck.dims_for(name)
-        _SD[name] = (dims, ck.synthetic_state_dict(dims, seed=0))
-    return _SD[name]
+        _SD[key] = (dims, ck.synthetic_state_dict(dims, seed=0, **kw))
+    return _SD[key]
 
 
 def bench_mel(eng, n_windows):
@@ -47,23 +50,33 @@ def bench_mel(eng, n_windows):
     return eng.log_mel(pcm), pcm.numel() // 160
 
 
-def check_windows_against_emulation(eng, dims, sd, mel, n_windows, probe, n_steps=12):
+def check_windows_against_emulation(eng, dims, sd, mel, n_windows, probe, n_steps=12, emu_key=None, min_clear=0.0):
     """Encoder output, teacher-forced logits and margin-gated greedy ids of the windows in `probe`, decoded inside the full
-    batch, against the bf16-emulating oracle run on those windows alone."""
+    batch, against the bf16-emulating oracle run on those windows alone.  `emu_key`: cache the emulation's encoder outputs
+    under this key (two engines that differ in launch configuration only share them; the decoder side is re-evaluated at each
+    engine's own key split).  `min_clear`:
+    the fraction of greedy steps whose emulated top-2 margin must exceed delta, i.e. where the arg-max itself is asserted."""
     tok = eng.tok
     assert eng.cross_form == "encoder_output"            # 32 rows and up: cross-attention on the encoder output
-    om = wo.OracleWhisper(dims, sd, emulate_bf16=True, cross_form=eng.cross_form)
+    # the emulation restates the stream kernel's online softmax at THIS engine's key split (oracle: _online_context)
+    om = wo.OracleWhisper(dims, sd, emulate_bf16=True, flash_tiles=True, cross_form=eng.cross_form, cross_key_splits=eng.cross_key_splits)
     mw = torch.stack([mel[:, w * 3000:(w + 1) * 3000].cpu() for w in probe])
     init = eng.initial_tokens(0)
     toks = torch.tensor([init + [100, 2000, 31337]] * len(probe))
+    o64 = wo.OracleWhisper(dims, sd, emulate_bf16=True, flash_tiles=True, acc_dtype=torch.float64, cross_form=eng.cross_form, cross_key_splits=eng.cross_key_splits)
+    if emu_key is not None and emu_key in _EMU:          # the encoder side does not depend on the launch configuration
+        xa, x64, mw0 = _EMU[emu_key]
+        assert torch.equal(mw0, mw)                      # (nor does the log-mel)
+    else:
+        with torch.no_grad():
+            xa = om.encode(mw)
+            x64 = o64.encode(mw[:1])                     # the noise floor: one window is enough
+        if emu_key is not None:
+            _EMU[emu_key] = (xa, x64, mw)
     with torch.no_grad():
-        xa = om.encode(mw)
         ref_lg = om.logits(toks, xa)
-        ref = wo.greedy_decode(om, xa, init, tok, eng.suppress_ids, max_new_tokens=n_steps)
-        o64 = wo.OracleWhisper(dims, sd, emulate_bf16=True, acc_dtype=torch.float64, cross_form=eng.cross_form)        # the noise floor: one window is enough
-        x64 = o64.encode(mw[:1])
         lg64 = o64.logits(toks[:1], x64)
-        del o64
+    del o64
     f_enc, f_lg = rms_err(x64, xa[:1]), rms_err(lg64, ref_lg[:1])
     got_xa = eng.encoder_output(n_windows).cpu()[probe]
     e_enc = rms_err(got_xa, xa)
@@ -98,25 +111,41 @@ def check_windows_against_emulation(eng, dims, sd, mel, n_windows, probe, n_step
                 clear += 1
                 assert chosen == int(row[0].argmax()), (w, i)
     print(f"greedy ids along the device path: {exact} of {len(probe) * n_steps} are the emulation's arg-max, {clear} with a margin above "
-          f"delta = {delta:.3f}; all within delta of the maximum")
+          f"delta = {delta:.3f} (arg-max asserted there: {100.0 * clear / (len(probe) * n_steps):.0f} % of the steps); all within delta of the maximum")
     assert exact >= len(probe) * n_steps // 2
-    return t, init, (xa, ref_lg)
+    assert clear >= min_clear * len(probe) * n_steps, (clear, len(probe) * n_steps)
+    return t, init, (xa, ref_lg, lg, f_lg)
 
 
-def test_large_v3_bf16_at_the_benchmarked_batch():
-    """configs[2] as benchmarked: max_batch = 64 (which fixes the cross-attention key split), 64 windows in one batch."""
+_LG_BY_LANES = {}
+
+
+@pytest.mark.parametrize("n_lanes", [4, 1])
+def test_large_v3_bf16_at_the_benchmarked_batch(n_lanes):
+    """configs[2] as benchmarked: max_batch = 64 and n_lanes = 4 -- bench.py's default engine configuration, which sizes the
+    cross-attention stream at ONE key split per row (64 workgroups, 47 tiles each, a single split through xattn_cproj_kernel) --
+    and the one-lane configuration beside it (4 key splits: 256 workgroups); 64 windows in one batch."""
     from whisper_amd.engine import WhisperEngine
     dims, sd = weights("large-v3")
-    eng = WhisperEngine(dims, sd, precision="bf16", max_batch=64)
+    eng = WhisperEngine(dims, sd, precision="bf16", max_batch=64, n_lanes=n_lanes)
     try:
+        assert eng.cross_key_splits == (1 if n_lanes == 4 else 4)
         mel, content = bench_mel(eng, 64)
         eng.encode(mel, 3000, mel.stride(0), content, 64)
-        t, init, (xa, ref_lg) = check_windows_against_emulation(eng, dims, sd, mel, 64, [0, 63])
-        # for the record: distance of the bf16 path from the plain fp32 oracle on the same two windows
-        om32 = wo.OracleWhisper(dims, sd)
-        with torch.no_grad():
-            x32 = om32.encode(torch.stack([mel[:, w * 3000:(w + 1) * 3000].cpu() for w in (0, 63)]))
-        print(f"bf16 emulation vs fp32 oracle, encoder output: {rms_err(xa, x32):.3e} (sharp weights)")
+        t, init, (xa, ref_lg, lg, f_lg) = check_windows_against_emulation(eng, dims, sd, mel, 64, [0, 63], emu_key=("large-v3", 0, 63))
+        # the two launch configurations round the partial contexts at different points (bf16 per key split): their logits
+        # differ by bf16 noise, bounded like the distance to the emulation (lanes change bf16 results, never fp32 ones)
+        _LG_BY_LANES[n_lanes] = lg
+        if len(_LG_BY_LANES) == 2:
+            e = rms_err(_LG_BY_LANES[1], _LG_BY_LANES[4])
+            print(f"logits at 1 vs 4 key splits: {e:.3e} = {e / f_lg:.2f} noise floors")
+            assert e < BF16_NOISE_FACTOR * f_lg
+        if n_lanes == 4:
+            # for the record: distance of the bf16 path from the plain fp32 oracle on the same two windows
+            om32 = wo.OracleWhisper(dims, sd)
+            with torch.no_grad():
+                x32 = om32.encode(torch.stack([mel[:, w * 3000:(w + 1) * 3000].cpu() for w in (0, 63)]))
+            print(f"bf16 emulation vs fp32 oracle, encoder output: {rms_err(xa, x32):.3e} (sharp weights)")
         # graph replay == eager launches at this batch
         e = eng.decode_greedy(64, init, max_new_tokens=12, use_graph=False)["tokens"].cpu()
         assert torch.equal(t, e)
@@ -155,6 +184,59 @@ def test_large_v3_beam5_on_15_windows():
         b3 = eng.decode_beam(3, init, beam_size=5, max_new_tokens=10)
         assert b3["tokens"] == b5["tokens"][:3]
         assert [[c[0] for c in cs] for cs in b3["candidates"]] == [[c[0] for c in cs] for cs in b5["candidates"][:3]]
+    finally:
+        eng.close()
+
+
+def test_large_v3_bf16_ids_on_well_conditioned_weights():
+    """The id-level check with teeth: large-v3 bf16 at the benchmarked engine configuration (max_batch 64, n_lanes 4 -> 1 key
+    split) on weights whose bf16 noise floor is a few 1e-3 (attn_gain 1: the floor of the sharp benchmark weights is 8 %, of
+    the order of their top-2 margins, so almost no step can be asserted there).  4 windows x 24 greedy steps inside the
+    batch of 64: along the device's path every id is THE arg-max of the emulation wherever the emulation's margin exceeds
+    delta = 6 floors x rms(logits) -- and that must hold for at least 80 % of the steps."""
+    from whisper_amd.engine import WhisperEngine
+    dims, sd = weights("large-v3", attn_gain=1.0)
+    eng = WhisperEngine(dims, sd, precision="bf16", max_batch=64, n_lanes=4)
+    try:
+        assert eng.cross_key_splits == 1
+        mel, content = bench_mel(eng, 64)
+        eng.encode(mel, 3000, mel.stride(0), content, 64)
+        check_windows_against_emulation(eng, dims, sd, mel, 64, [0, 21, 42, 63], n_steps=24, min_clear=0.8)
+    finally:
+        eng.close()
+
+
+def test_large_v3_fp32_token_exact():
+    """north_star: "fp32 greedy tokens identical to the reference" at the TARGET model.  fp32 engine, large-v3 dimensions
+    (d 1280, 20 heads, 32 + 32 layers, 128 mel bins, vocab 51 866): gemm_f32_tile_kernel, attn_rows_kernel, the K/V-cache
+    cross-attention and the sampler at full width.  2 windows, 16 greedy steps: ids bit-exact against the fp32 oracle,
+    cumulative log-probabilities to 1e-4, encoder output and logits to the fp32 tolerance."""
+    from whisper_amd.engine import WhisperEngine
+    dims, sd = weights("large-v3", eot_boost=3.0)
+    eng = WhisperEngine(dims, sd, precision="fp32", max_batch=2)
+    try:
+        assert eng.cross_form == "kv"
+        tok = eng.tok
+        mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(s), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000] for s in (0, 1)])
+        init = wo.initial_tokens(tok, 0)
+        om = wo.OracleWhisper(dims, sd)
+        with torch.no_grad():
+            xa = om.encode(mels)
+            ref = wo.greedy_decode(om, xa, init, tok, eng.suppress_ids, max_new_tokens=16)
+        eng.encode_windows(mels)
+        got_xa = eng.encoder_output(2).cpu()
+        e_enc = float((got_xa - xa).abs().max() / xa.abs().max())
+        r = eng.decode_greedy(2, init, max_new_tokens=16)
+        t, n = r["tokens"].cpu(), r["n_tokens"].cpu()
+        got = [t[b, len(init):len(init) + int(n[b])].tolist() for b in range(2)]
+        print(f"\nlarge-v3 fp32: encoder output max rel err {e_enc:.2e}; min top-2 margin {ref['margins'].min():.3e}; ids {got[0][:8]}...")
+        assert e_enc < 2e-4
+        assert ref["margins"].min() > 1e-3, "fixture argmax is ill-conditioned; pick another seed"
+        assert got == ref["tokens"]
+        np.testing.assert_allclose(r["sum_logprobs"].cpu().numpy(), ref["sum_logprobs"], rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(r["no_speech_probs"].cpu().numpy(), ref["no_speech_probs"], rtol=1e-3)
+        e2 = eng.decode_greedy(2, init, max_new_tokens=16, use_graph=False)["tokens"].cpu()
+        assert torch.equal(e2, t)
     finally:
         eng.close()
 
