@@ -53,6 +53,10 @@ def parse():
     p.add_argument("--no-profile-pass", action="store_true", help="skip the event-bracketed eager pass (PMC runs)")
     p.add_argument("--lanes", type=int, default=4, help="batches in flight per GPU: engine replicas, each on its own host thread and stream "
                    "(whisper_amd/lanes.py); step i runs on lane i mod lanes.  1 = one batch at a time (per-kernel profiles)")
+    p.add_argument("--separate-weights", action="store_true", help="A/B: every lane uploads its own copy of the weights (round 2's layout) "
+                   "instead of sharing lane 0's (wx_create_shared)")
+    p.add_argument("--no-single-batch", action="store_true", help="skip the single_batch leg (a few steps of ONE batch at a time on an engine "
+                   "sized for the whole GPU, after the timed region)")
     p.add_argument("--dry-run", action="store_true", help="launcher rehearsal: every rank reports its rank environment and exits before touching the GPU")
     return p.parse_args()
 
@@ -206,7 +210,7 @@ def main():
     if args.lanes < 1:
         raise SystemExit("--lanes must be >= 1")
     lanes = EngineLanes.create(lambda n: WhisperEngine(dims, sd, precision=args.precision, max_batch=B * max(1, args.beam), device=local_rank, n_lanes=n),
-                               args.lanes)
+                               args.lanes, share_weights=not args.separate_weights)
     eng = lanes.engines[0]
     prompt = eng.initial_tokens(0)
 
@@ -313,6 +317,33 @@ def main():
                 ms_i, n_i = e_i.last_profile()
                 prof_ms += ms_i; prof_n += n_i
 
+        # single_batch leg: ONE batch at a time on an engine sized for the whole GPU (n_lanes = 1: the stream kernel at one full
+        # round of workgroups), same weights (a replica of lane 0's engine).  Not part of `value`; it is the latency-side figure.
+        single = None
+        if not args.no_single_batch and not args.beam and lanes.n_lanes > 1 and rank == 0:
+            solo = eng.replica(n_lanes=1)
+            try:
+                back(solo, front())                                    # capture its graph
+                torch.cuda.synchronize(dev)
+                n_solo = 3
+                ts = time.perf_counter()
+                for _ in range(n_solo):
+                    back(solo, front())
+                torch.cuda.synchronize(dev)
+                solo_s = (time.perf_counter() - ts) / n_solo
+                ms_f, ms_b = [], []
+                back(solo, front(ms_f), True, 0, ms_b)
+                torch.cuda.synchronize(dev)
+                back(solo, front(), False, 8)                          # eager, event-bracketed stream launches, alone on the GPU
+                torch.cuda.synchronize(dev)
+                solo_prof_ms, solo_prof_n = solo.last_profile()
+                single = {"lanes": 1, "key_splits": solo.cross_key_splits, "steps": n_solo, "ms_per_step": solo_s * 1e3,
+                          "value": B * 30.0 / solo_s, "unit": "audio-sec/sec",
+                          "stages_ms": {"mel": ms_f[0].elapsed_time(ms_f[1]), "encoder": ms_b[0].elapsed_time(ms_b[1]), "decode": ms_b[1].elapsed_time(ms_b[2])},
+                          "kernel_avg_launch_ms": solo_prof_ms / max(1, solo_prof_n), "kernel_launches_timed": solo_prof_n}
+            finally:
+                solo.close()
+
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         wdist.all_reduce_max(t)
@@ -385,6 +416,23 @@ def main():
             "decode": {"ms": st_ms[2], "achieved_GBs": dec_bytes / st_ms[2] / 1e6, "peak_GBs": HBM_PEAK_GBS, "bound": "hbm",
                        "ms_per_token_step": st_ms[2] / max(1, steps_per_window + len(prompt) - 1)},
         }
+        out["stages"]["conditions"] = (f"one more batch after the timed region, ALONE on the GPU, on lane 0's engine (the benchmarked engine shape: "
+                                       f"{eng.cross_key_splits} key split(s) per row of the stream kernel); in the timed region {lanes.n_lanes} batches overlap")
+        # the whole step against the HBM roofline: algorithmic bytes of one batch (mel + every decode position's weights, encoder
+        # output and self-attention cache; the encoder's own traffic is not counted: it is the MFMA-bound stage) over the measured
+        # time per batch, and the encoder's FLOPs that run inside the same interval
+        step_bytes = mel_bytes + dec_bytes
+        out["roofline"]["step"] = {"bytes": step_bytes, "flops": enc_flop, "ms_per_step": elapsed / args.steps * 1e3,
+                                   "hbm_GBs": step_bytes / (elapsed / args.steps) / 1e9,
+                                   "hbm_frac": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                                   "mfma_TFLOPs_in_the_same_interval": enc_flop / (elapsed / args.steps) / 1e12}
+        if single is not None:
+            single["kernel_achieved_GBs"] = bytes_per_launch / (single["kernel_avg_launch_ms"] * 1e-3) / 1e9 if single["kernel_launches_timed"] else 0.0
+            single["kernel_frac"] = single["kernel_achieved_GBs"] / HBM_PEAK_GBS
+            out["single_batch"] = single
+        out["config"]["weights_shared_by_lanes"] = not args.separate_weights
+        out["config"]["weight_bytes_per_gpu"] = sum(e_i.weight_bytes for e_i in lanes.engines)
+        out["config"]["workspace_bytes_per_gpu"] = sum(e_i.workspace_bytes for e_i in lanes.engines)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(dims, sd, tok, eng.suppress_ids, steps_per_window, args.cpu_decode_steps)
         print(json.dumps(out), flush=True)

@@ -13,7 +13,8 @@
  * wx_mel_stage1, wx_mel_stage2, wx_pcm16_to_f32 and wx_resample_pcm16 only read the engine's tables and work on the caller's
  * buffers and stream, so they may run (from another host thread, on another stream) while the engine encodes or decodes.
  * Engines are independent of one another: several of them, on one GPU or on several, may be driven from different host threads
- * at the same time (whisper_amd/lanes.py keeps two batches in flight per GPU that way).
+ * at the same time (whisper_amd/lanes.py keeps several batches in flight per GPU that way, on one copy of the weights:
+ * wx_create_shared).
  */
 #ifndef WHISPER_AMD_H
 #define WHISPER_AMD_H
@@ -85,6 +86,15 @@ int wx_set_mel_filters(wx_engine* e, const float* h_filters /* [n_mels][201] */)
 int wx_set_suppress_tokens(wx_engine* e, const int32_t* h_ids, int32_t n);
 int wx_finalize(wx_engine* e);
 
+/* a second engine on the SAME weights (still whisper.load_model, ref:speech_recognition.py:22: the reference holds ONE model object
+ * however many calls use it).  `parent` must be finalized; cfg's model dimensions, precision and device must equal the parent's,
+ * max_batch and n_lanes are the new engine's own (but must select the same cross-attention form, wx_cross_attention_form).  The
+ * new engine comes back finalized: it owns workspace, caches, decode state and graph, shares the parent's weight allocations
+ * (they are freed with the LAST engine that uses them, whatever the order of the wx_destroy calls), starts from the parent's
+ * suppress list (wx_set_suppress_tokens changes its own copy only) and reports wx_weight_bytes() == 0.  This is how
+ * whisper_amd/lanes.py keeps several batches in flight per GPU on one copy of the weights. */
+int wx_create_shared(const wx_engine* parent, const wx_config* cfg, wx_engine** out);
+
 /* replaces the tail of whisper.load_audio (inside model.transcribe, ref:speech_recognition.py:55): the reference's audio
  * front end hands over 16 kHz mono s16le PCM (ref:app/audio/processor.py:141-143) and upstream divides by 32768 on the
  * host; here the int16 samples are uploaded as they are (half the PCIe bytes) and converted on the device.
@@ -138,6 +148,12 @@ int wx_encode(wx_engine* e, const float* d_mel, int64_t win_stride, int64_t row_
               int32_t B, void* stream);
 int wx_get_encoder_output(wx_engine* e, int32_t B, float* d_out, void* stream);
 
+/* serves upstream's decode_with_fallback (Whisper.transcribe inside ref:speech_recognition.py:55 re-decodes ONLY the windows whose
+ * compression-ratio / log-probability checks failed): keep n windows of the last wx_encode -- slot i takes the encoder results of
+ * slot h_src[i]; h_src strictly ascending, i <= h_src[i] < windows of the last wx_encode -- so that the next decode call runs
+ * on those windows alone (rows 0..n-1).  Device-to-device copies on `stream`; afterwards the engine holds n windows. */
+int wx_compact_windows(wx_engine* e, const int32_t* h_src, int32_t n, void* stream);
+
 /* replaces DecodingTask.run greedy (temperature 0) for the B windows of the last wx_encode.
  * h_prompt: n_prompt ids shared by all windows.  Outputs (device): d_tokens [B][n_text_ctx + 1] int32 (prompt +
  * sampled ids, EOT-padded after the end), d_n_tokens [B] (count of sampled ids before EOT), d_sum_logprob [B],
@@ -188,7 +204,7 @@ int wx_get_profile(wx_engine* e, double* total_ms, int64_t* launches);
 
 /* introspection for benchmarks.  wx_weight_bytes counts what wx_finalize left resident: the weights in the engine dtype and,
  * on bf16 engines, a second copy of the decoder projections and the token embedding in the load order of the decode GEMMs
- * (about half as much again). */
+ * (about half as much again); 0 for an engine made by wx_create_shared (it owns none). */
 int64_t wx_weight_bytes(wx_engine* e);
 int64_t wx_workspace_bytes(wx_engine* e);
 /* which form of the decoder cross-attention this engine's greedy / sampling decode runs: 0 = on cached per-layer K/V (upstream's

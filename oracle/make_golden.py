@@ -15,9 +15,12 @@ Two kinds of vectors are written:
                    1816-2112): masks / argmax on seeded logit rows and token histories that reach every branch, and a
                    greedy loop (HF model forward + HF processors, argmax, EOT stickiness) on the seeded micro model.
                    They pin ``apply_logit_filters`` / ``greedy_decode`` of the oracle to an independent implementation.
+  * ``hf_sequential.json`` — transformers' long-form helpers (``_retrieve_segment``, ``_need_fallback``,
+                   ``_retrieve_avg_logprobs``) on crafted id sequences: they pin the segment / seek / fallback rules of the
+                   sequential loop (oracle AND whisper_amd/longform.py) to an independent implementation.
   * ``oracle_*`` — outputs of the oracle itself (greedy ids, log-probs, margins); they pin the HIP path on the GPU box
-                   and guard the oracle against regressions.  Beam search and the sequential long-form loop have no
-                   independent implementation in this container (transformers' differ by design): [upstream-recall] only.
+                   and guard the oracle against regressions.  Beam search has no independent implementation in this
+                   container (transformers' differs by design): [upstream-recall] only.
 Inputs are regenerated from seeds at test time (whisper_amd.checkpoint.synthetic_state_dict, oracle.varied_audio), so
 the fixtures hold outputs only and stay small.
 """
@@ -181,7 +184,95 @@ def make_hf_greedy(name="micro", n_windows=4):
     np.savez_compressed(os.path.join(OUT, f"hf_greedy_{name}.npz"), **out)
 
 
+def sequential_cases(tb):
+    """Crafted id sequences of one window (after the prompt, EOT stripped) x (seek, frames in the window)."""
+    seqs = {
+        "no_timestamps": [500, 501, 502],
+        "one_trailing_timestamp": [tb, 500, 501, tb + 120],
+        "pairs_then_open_text": [tb, 500, tb + 100, tb + 100, 600, 601, tb + 250, tb + 250, 700],
+        "pairs_then_lone_ending": [tb, 500, tb + 100, tb + 100, 600, tb + 300],
+        "only_zero_timestamp": [tb],
+        "ends_at_30s_lone": [tb, 500, tb + 1500],
+        "ends_at_30s_pair": [tb, 500, tb + 1500, tb + 1500],
+        "timestamp_in_the_middle": [500, tb + 50, 501],
+        "opens_with_a_pair": [tb + 10, tb + 10, 500, tb + 90, tb + 90],
+        "pair_at_the_very_start_only": [tb, tb, 500, 501],
+        "three_segments_lone_ending": [tb + 2, 400, tb + 40, tb + 40, 401, 402, tb + 99, tb + 99, 403, tb + 140],
+        "text_then_pair_then_timestamp_text": [300, tb + 20, tb + 20, tb + 30, 301],
+        "single_text_token": [777],
+        "two_timestamps_only": [tb + 5, tb + 5],
+    }
+    windows = [(0, 3000), (4200, 3000), (9000, 1234)]
+    return seqs, windows
+
+
+def make_sequential_fixtures():
+    """hf_sequential.json: transformers' long-form helpers on crafted inputs -- ``_retrieve_segment`` (segment cuts, times, seek
+    advance; hf:models/whisper/generation_whisper.py:1977-2074), ``_need_fallback`` (:1243-1287) and ``_retrieve_avg_logprobs``
+    (:1958-1974).  They pin oracle.split_segments / fallback_decision / avg_logprob and whisper_amd.longform's counterparts to an
+    independent implementation.  Known differences between transformers and upstream openai-whisper [upstream-recall], kept
+    in the fixture as `hf_differs`:
+      * tokens of the LAST segment when the ids do not end in a lone timestamp: HF keeps the second timestamp of the closing
+        pair in it (slices[-1] += 1, "to know it was no single ending"), upstream does not; times and seek agree;
+      * HF computes the compression ratio on token BYTES, upstream on the decoded TEXT: only the predicate on the value is pinned;
+      * HF cancels a fallback for silence only when the log-probability is ALSO below its threshold, upstream whenever
+        no_speech_prob > threshold;
+      * should_skip at avg_logprob == threshold exactly: HF needs `<`, upstream skips unless `>`."""
+    import json
+    import types
+    from transformers.generation.logits_process import WhisperNoSpeechDetection
+    from transformers.models.whisper.generation_whisper import WhisperGenerationMixin as G
+    n_vocab = 51865
+    tok = ck.special_tokens_for(n_vocab)
+    tb = tok.timestamp_begin
+    seqs, windows = sequential_cases(tb)
+    out = {"timestamp_begin": tb, "time_precision": 0.02, "input_stride": 2, "segments": [], "fallback": [], "avg_logprob": []}
+    for name, ids in seqs.items():
+        for seek, frames in windows:
+            segs, off = G._retrieve_segment(
+                seek_sequence=torch.tensor(ids), seek_outputs=[None], time_offset=torch.tensor([seek * 0.02 / 2], dtype=torch.float64),
+                timestamp_begin=tb, seek_num_frames=torch.tensor([frames]), time_precision=0.02, time_precision_features=0.01,
+                input_stride=2, prev_idx=0, idx=0, return_token_timestamps=False, decoder_input_ids=torch.zeros((1, 4), dtype=torch.long))
+            out["segments"].append({"case": name, "ids": ids, "seek": seek, "frames": frames,
+                                    "hf": [{"start": float(sg["start"]), "end": float(sg["end"]), "tokens": sg["tokens"].tolist()} for sg in segs],
+                                    "hf_advance": int(off)})
+    # fallback predicates: a window of 30 ids whose token bytes compress badly (random ids) or well (one id repeated), each
+    # id with log-probability L exactly (the scores are a normalised log-probability row), no-speech probability P
+    host = type("Host", (G,), {})()
+    g = torch.Generator().manual_seed(0)
+    rand_ids = torch.randint(0, 50000, (30,), generator=g)
+    same_ids = torch.full((30,), 1234)
+    for ids_name, ids in (("incompressible", rand_ids), ("repetitive", same_ids)):
+        for L in (-1.5, -1.0, -0.5):
+            scores = []
+            for t in ids.tolist():
+                row = torch.full((n_vocab,), float(np.log((1.0 - np.exp(L)) / (n_vocab - 1))), dtype=torch.float64)
+                row[t] = L
+                scores.append(row)
+            for P in (0.1, 0.6, 0.9):
+                det = object.__new__(WhisperNoSpeechDetection)
+                det._no_speech_prob = torch.tensor([P])       # what its __call__ leaves (logits_process.py:2110)
+                gc = types.SimpleNamespace(compression_ratio_threshold=2.4, logprob_threshold=-1.0, no_speech_threshold=0.6)
+                nf, skip = host._need_fallback(ids, [{"scores": scores}], 0, [det], gc, n_vocab, 0.0)
+                out["fallback"].append({"ids": ids_name, "compression_ratio": float(G._retrieve_compression_ratio(ids, n_vocab)),
+                                        "avg_logprob": float(G._retrieve_avg_logprobs(scores, ids, 0.0)), "no_speech_prob": P,
+                                        "hf_needs_fallback": bool(nf), "hf_should_skip": bool(skip)})
+    # avg_logprob: n sampled ids + EOT, seeded logits: HF divides the sum of ALL n + 1 log-probabilities by n + 1
+    for n in (1, 7, 30):
+        g = torch.Generator().manual_seed(100 + n)
+        logits = torch.randn((n + 1, 997), generator=g, dtype=torch.float64) * 2.0
+        ids = torch.cat([torch.randint(0, 996, (n,), generator=g), torch.tensor([996])])     # 996 plays EOT
+        lp = torch.log_softmax(logits, -1)[torch.arange(n + 1), ids]
+        out["avg_logprob"].append({"n_tokens": n, "sum_logprob": float(lp.sum()),
+                                   "hf": float(G._retrieve_avg_logprobs([r for r in logits], ids, 0.0))})
+    with open(os.path.join(OUT, "hf_sequential.json"), "w") as f:
+        json.dump(out, f, indent=0)
+
+
 def main():
+    if sys.argv[1:] == ["sequential"]:
+        make_sequential_fixtures()
+        return
     from transformers import WhisperFeatureExtractor
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -238,6 +329,7 @@ def main():
         np.savez_compressed(os.path.join(OUT, f"oracle_greedy_{name}.npz"), **out)
     make_rule_fixtures()
     make_hf_greedy("micro")
+    make_sequential_fixtures()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -693,6 +693,73 @@ def compression_ratio(text: str) -> float:
     return len(b) / len(zlib.compress(b))
 
 
+def avg_logprob(sum_logprob: float, n_tokens: int) -> float:
+    """Upstream ``DecodingResult.avg_logprob = sum_logprob / (len(tokens) + 1)``: the EOT step counts
+    (hf:models/whisper/generation_whisper.py:1958-1974 ``_retrieve_avg_logprobs``: "don't remove the eos token logprob")."""
+    return float(sum_logprob) / (int(n_tokens) + 1)
+
+
+def fallback_decision(compression_ratio_value: float, avg_logprob_value: float, no_speech_prob: float,
+                      compression_ratio_threshold: Optional[float] = 2.4, logprob_threshold: Optional[float] = -1.0,
+                      no_speech_threshold: Optional[float] = 0.6):
+    """(needs_fallback, should_skip) of one decoded window [upstream-recall: ``decode_with_fallback`` and the no-speech skip of
+    ``Whisper.transcribe``]; HF's counterpart is hf:models/whisper/generation_whisper.py:1243-1287 ``_need_fallback``.
+    Where the two differ, upstream is followed (tests/golden/hf_sequential.json records the cases): upstream cancels the
+    fallback whenever no_speech_prob > threshold, HF only if the log-probability is ALSO below its threshold; upstream skips
+    a silent window unless avg_logprob > threshold, HF only if avg_logprob < threshold (they differ at equality)."""
+    needs_fallback = False
+    if compression_ratio_threshold is not None and compression_ratio_value > compression_ratio_threshold:
+        needs_fallback = True
+    if logprob_threshold is not None and avg_logprob_value < logprob_threshold:
+        needs_fallback = True
+    if no_speech_threshold is not None and no_speech_prob > no_speech_threshold:
+        needs_fallback = False
+    should_skip = False
+    if no_speech_threshold is not None:
+        should_skip = no_speech_prob > no_speech_threshold
+        if logprob_threshold is not None and avg_logprob_value > logprob_threshold:
+            should_skip = False
+    return needs_fallback, should_skip
+
+
+def split_segments(tokens: Sequence[int], timestamp_begin: int, seek: int, segment_size: int):
+    """The ids one window decoded to (after the prompt, EOT stripped) -> ``([(start s, end s, ids)], next seek)``
+    [upstream-recall: the segment loop of ``Whisper.transcribe``]; HF's counterpart, which tests/golden/hf_sequential.json
+    pins this against, is hf:models/whisper/generation_whisper.py:1977-2074 ``_retrieve_segment``.  Ids are cut after every
+    pair of consecutive timestamps; a single timestamp at the very end means "no speech after it" (seek moves on by the
+    whole window), otherwise seek moves to the last timestamp of a pair (x 2 mel frames per timestamp unit) and everything
+    after it is decoded again; with no pair at all the window is one segment that ends at its last timestamp, if it has one
+    other than <|0.00|>, else at the window's end."""
+    tokens = list(tokens)
+    tb = timestamp_begin
+    time_offset = seek * HOP_LENGTH / SAMPLE_RATE
+    is_ts = [t >= tb for t in tokens]
+    single_timestamp_ending = is_ts[-2:] == [False, True]
+    consecutive = [i + 1 for i in range(len(tokens) - 1) if is_ts[i] and is_ts[i + 1]]
+    out = []
+    if consecutive:
+        slices = list(consecutive)
+        if single_timestamp_ending:
+            slices.append(len(tokens))
+        last_slice = 0
+        for cur in slices:
+            sl = tokens[last_slice:cur]
+            out.append((time_offset + (sl[0] - tb) * 0.02, time_offset + (sl[-1] - tb) * 0.02, sl))
+            last_slice = cur
+        if single_timestamp_ending:
+            seek_next = seek + segment_size
+        else:
+            seek_next = seek + (tokens[last_slice - 1] - tb) * 2
+    else:
+        duration = segment_size * HOP_LENGTH / SAMPLE_RATE
+        ts = [t for t in tokens if t >= tb]
+        if ts and ts[-1] != tb:
+            duration = (ts[-1] - tb) * 0.02
+        out.append((time_offset, time_offset + duration, tokens))
+        seek_next = seek + segment_size
+    return out, seek_next
+
+
 def transcribe_sequential(model: OracleWhisper, audio: np.ndarray, tok, suppress_ids: Sequence[int], decode_text,
                           language_index: int = 0, initial_prompt_ids: Optional[Sequence[int]] = None,
                           compression_ratio_threshold: Optional[float] = 2.4, logprob_threshold: Optional[float] = -1.0,
@@ -716,9 +783,7 @@ def transcribe_sequential(model: OracleWhisper, audio: np.ndarray, tok, suppress
     windows = 0
     tb = tok.timestamp_begin
     while seek < content_frames:
-        time_offset = seek * HOP_LENGTH / SAMPLE_RATE
         segment_size = min(N_FRAMES, content_frames - seek)
-        segment_duration = segment_size * HOP_LENGTH / SAMPLE_RATE
         mel_segment = pad_or_trim_frames(mel[:, seek:seek + segment_size])
         prompt = all_tokens[prompt_reset_since:]
         init = initial_tokens(tok, language_index, without_timestamps=False, prompt_ids=prompt, n_text_ctx=dims.n_text_ctx)
@@ -727,52 +792,19 @@ def transcribe_sequential(model: OracleWhisper, audio: np.ndarray, tok, suppress
                               without_timestamps=False)
         windows += 1
         tokens = r["tokens"][0]
-        avg_logprob = float(r["avg_logprobs"][0]); no_speech_prob = float(r["no_speech_probs"][0])
+        avg_lp = avg_logprob(float(r["sum_logprobs"][0]), len(tokens)); no_speech_prob = float(r["no_speech_probs"][0])
         text = decode_text(tokens).strip()
         cr = compression_ratio(text) if text else 0.0
-        needs_fallback = False
-        if compression_ratio_threshold is not None and cr > compression_ratio_threshold:
-            needs_fallback = True
-        if logprob_threshold is not None and avg_logprob < logprob_threshold:
-            needs_fallback = True
-        if no_speech_threshold is not None and no_speech_prob > no_speech_threshold:
-            needs_fallback = False
-        if no_speech_threshold is not None:
-            should_skip = no_speech_prob > no_speech_threshold
-            if logprob_threshold is not None and avg_logprob > logprob_threshold:
-                should_skip = False
-            if should_skip:
-                seek += segment_size
-                continue
-        current: List[Dict[str, object]] = []
-
-        def new_segment(start, end, toks):
-            return {"seek": seek, "start": start, "end": end, "tokens": list(toks), "text": decode_text([t for t in toks if t < tok.eot]),
-                    "temperature": 0.0, "avg_logprob": avg_logprob, "compression_ratio": cr, "no_speech_prob": no_speech_prob,
-                    "needs_fallback": needs_fallback}
-        is_ts = [t >= tb for t in tokens]
-        single_timestamp_ending = is_ts[-2:] == [False, True]
-        consecutive = [i + 1 for i in range(len(tokens) - 1) if is_ts[i] and is_ts[i + 1]]
-        if consecutive:
-            slices = list(consecutive)
-            if single_timestamp_ending:
-                slices.append(len(tokens))
-            last_slice = 0
-            for cur in slices:
-                sl = tokens[last_slice:cur]
-                current.append(new_segment(time_offset + (sl[0] - tb) * 0.02, time_offset + (sl[-1] - tb) * 0.02, sl))
-                last_slice = cur
-            if single_timestamp_ending:
-                seek_next = seek + segment_size
-            else:
-                seek_next = seek + (tokens[last_slice - 1] - tb) * 2
-        else:
-            duration = segment_duration
-            ts = [t for t in tokens if t >= tb]
-            if ts and ts[-1] != tb:
-                duration = (ts[-1] - tb) * 0.02
-            current.append(new_segment(time_offset, time_offset + duration, tokens))
-            seek_next = seek + segment_size
+        needs_fallback, should_skip = fallback_decision(cr, avg_lp, no_speech_prob, compression_ratio_threshold, logprob_threshold,
+                                                        no_speech_threshold)
+        if should_skip:
+            seek += segment_size
+            continue
+        pieces, seek_next = split_segments(tokens, tb, seek, segment_size)
+        current: List[Dict[str, object]] = [
+            {"seek": seek, "start": start, "end": end, "tokens": list(toks), "text": decode_text([t for t in toks if t < tok.eot]),
+             "temperature": 0.0, "avg_logprob": avg_lp, "compression_ratio": cr, "no_speech_prob": no_speech_prob,
+             "needs_fallback": needs_fallback} for start, end, toks in pieces]
         for sg in current:
             if sg["start"] == sg["end"] or sg["text"].strip() == "":
                 sg["text"] = ""; sg["tokens"] = []

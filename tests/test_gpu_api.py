@@ -544,3 +544,126 @@ def test_cross_attention_grid_is_a_function_of_max_batch_and_lanes(max_batch, n_
             assert eng.cross_key_splits == splits
     finally:
         eng.close()
+
+
+def test_replicas_share_one_copy_of_the_weights():
+    """wx_create_shared: a replica owns workspace, caches and graph but no weights (wx_weight_bytes 0); it decodes the ids of
+    its parent, its own max_batch / suppress list are its own, and it outlives the parent (the weights are freed with the last
+    engine that uses them)."""
+    from whisper_amd.engine import WhisperEngine
+    dims = ck.dims_for("micro")
+    sd = ck.synthetic_state_dict(dims, seed=0, eot_boost=3.0)
+    for precision in ("fp32", "bf16"):
+        parent = WhisperEngine(dims, sd, precision=precision, max_batch=4)
+        rep = parent.replica()
+        small = parent.replica(max_batch=2)
+        try:
+            assert parent.weight_bytes > 0 and rep.weight_bytes == 0 and small.weight_bytes == 0
+            assert rep.workspace_bytes == parent.workspace_bytes and small.workspace_bytes < parent.workspace_bytes
+            mels = _mels(dims, range(4))
+            init = parent.initial_tokens(0)
+            parent.encode_windows(mels)
+            want = parent.decode_greedy(4, init, max_new_tokens=12)
+            rep.encode_windows(mels)
+            got = rep.decode_greedy(4, init, max_new_tokens=12)
+            assert torch.equal(got["tokens"], want["tokens"]) and torch.equal(got["sum_logprobs"], want["sum_logprobs"])
+            # a replica's suppress list is its own
+            first = int(want["tokens"][0, len(init)])
+            rep.set_suppress_ids(list(parent.suppress_ids) + [first])
+            rep.encode_windows(mels)
+            assert int(rep.decode_greedy(4, init, max_new_tokens=2)["tokens"][0, len(init)]) != first
+            parent.encode_windows(mels)
+            assert torch.equal(parent.decode_greedy(4, init, max_new_tokens=12)["tokens"], want["tokens"])
+            # the parent goes first: the replicas keep the weights alive
+            parent.close()
+            small.encode_windows(mels[2:4])
+            got2 = small.decode_greedy(2, init, max_new_tokens=12)
+            assert torch.equal(got2["tokens"], want["tokens"][2:4])
+            with pytest.raises(Exception):
+                parent.replica()
+        finally:
+            parent.close(); rep.close(); small.close()
+    # a replica must select the parent's cross-attention form (its weight layouts): bf16 below / above 32 rows differ
+    parent = WhisperEngine(dims, sd, precision="bf16", max_batch=4)
+    try:
+        with pytest.raises(Exception, match="cross-attention form"):
+            parent.replica(max_batch=64)
+    finally:
+        parent.close()
+
+
+@pytest.mark.parametrize("precision,xattn", [("fp32", False), ("bf16", False), ("bf16", True)])
+def test_compact_windows_then_decode_only_those(precision, xattn):
+    """wx_compact_windows: after keeping windows (1, 3) of four, a 2-row decode gives exactly the ids, log-probabilities and
+    no-speech probabilities those windows had in the batch of four (every form of the decoder's cross-attention moves its
+    per-window state); bad index lists are refused and leave the engine usable."""
+    from whisper_amd.engine import WhisperEngine
+    dims = ck.dims_for("micro")
+    sd = ck.synthetic_state_dict(dims, seed=0, eot_boost=3.0)
+    if xattn:
+        os.environ["WX_XATTN"] = "1"
+    try:
+        eng = WhisperEngine(dims, sd, precision=precision, max_batch=4)
+    finally:
+        os.environ.pop("WX_XATTN", None)
+    try:
+        assert eng.cross_form == ("encoder_output" if xattn else "kv")
+        mels = _mels(dims, range(4))
+        init = eng.initial_tokens(0)
+        eng.encode_windows(mels)
+        want = eng.decode_greedy(4, init, max_new_tokens=12)
+        enc4 = eng.encoder_output(4)
+        for bad in ([3, 1], [1, 1], [0, 4], [-1], [1, 2, 3, 3]):
+            with pytest.raises(Exception):
+                eng.compact_windows(bad)
+        eng.compact_windows([1, 3])
+        got = eng.decode_greedy(2, init, max_new_tokens=12)
+        for k in ("tokens", "sum_logprobs", "no_speech_probs", "n_tokens"):
+            assert torch.equal(got[k], want[k][[1, 3]]), k
+        assert torch.equal(eng.encoder_output(2), enc4[[1, 3]])
+        with pytest.raises(Exception):
+            eng.decode_greedy(3, init, max_new_tokens=2)          # the engine now holds two windows
+        eng.compact_windows([1])
+        one = eng.decode_greedy(1, init, max_new_tokens=12)
+        assert torch.equal(one["tokens"][0], want["tokens"][3])
+    finally:
+        eng.close()
+
+
+def test_temperature_fallback_redecodes_only_the_failed_files():
+    """Sequential mode, three one-window files, a log-probability threshold placed between their T = 0 results so that exactly
+    one of them fails: the second attempt (T = 0.2) decodes ONE row (the failed window, moved to slot 0), and the two files
+    that passed keep the segments of the T = 0 decode exactly."""
+    from oracle import whisper_oracle as wo
+    from whisper_amd.engine import WhisperEngine
+    from whisper_amd.longform import transcribe_sequential
+    from whisper_amd.tokenizer import Tokenizer
+    dims = ck.dims_for("micro")
+    sd = ck.synthetic_state_dict(dims, seed=0, eot_boost=3.0)
+    eng = WhisperEngine(dims, sd, precision="fp32", max_batch=4)
+    try:
+        dec = Tokenizer(dims.n_vocab).decode
+        audios = [wo.varied_audio(40 + i, 16000 * 20) for i in range(3)]
+        base = transcribe_sequential(eng, audios, dec, language_index=0, temperatures=(0.0,), max_new_tokens=16, compression_ratio_threshold=None)
+        lps = [f["segments"][0]["avg_logprob"] for f in base]
+        order = sorted(range(3), key=lambda i: lps[i])
+        thr = 0.5 * (lps[order[0]] + lps[order[1]])               # only the least likely file falls below
+        assert lps[order[0]] < thr < lps[order[1]]
+        calls = []
+        orig = eng.decode_rows
+
+        def spy(prompts, **kw):
+            calls.append((len(prompts), kw.get("temperature")))
+            return orig(prompts, **kw)
+        eng.decode_rows = spy
+        got = transcribe_sequential(eng, audios, dec, language_index=0, temperatures=(0.0, 0.2), max_new_tokens=16,
+                                    compression_ratio_threshold=None, logprob_threshold=thr, no_speech_threshold=None)
+        assert calls == [(3, 0.0), (1, 0.2)]
+        for i in range(3):
+            if i == order[0]:
+                assert all(s["temperature"] == 0.2 for s in got[i]["segments"])
+            else:
+                assert [(s["tokens"], s["start"], s["end"], s["temperature"]) for s in got[i]["segments"]] == \
+                       [(s["tokens"], s["start"], s["end"], 0.0) for s in base[i]["segments"]]
+    finally:
+        eng.close()

@@ -214,3 +214,77 @@ def test_resampler_restatement_matches_scipy(rate):
         assert np.array_equal(q * 32768.0, np.rint(q * 32768.0)) and np.abs(q - ref).max() <= 0.5 / 32768 + 5e-7
         assert np.array_equal(wo.resample_pcm16(pcm[:, 0], rate, False), wo.resample_pcm16(pcm[:, :1], rate, False))
 
+
+
+# ---- the sequential long-form loop's rules against transformers' helpers (tests/golden/hf_sequential.json) -----------------
+
+def _hf_sequential():
+    import json
+    with open(os.path.join(G, "hf_sequential.json")) as f:
+        return json.load(f)
+
+
+def test_segment_cuts_and_seek_match_hf_retrieve_segment():
+    """Segment boundaries, start / end times and the seek advance of BOTH restatements -- the oracle's ``split_segments`` and
+    the product's ``whisper_amd.longform._split_segments`` -- equal ``WhisperGenerationMixin._retrieve_segment`` on crafted
+    id sequences: no timestamps, one trailing timestamp, consecutive pairs with open text or a lone ending after them,
+    <|0.00|> only, 30.00 s, a pair at the very start, timestamps only; at seek 0, mid-file, and in a short last window.
+    The one designed difference: when the ids do not end in a lone timestamp, HF leaves the second timestamp of the closing
+    pair in the last segment's ids (hf:models/whisper/generation_whisper.py:2004-2006), upstream does not."""
+    from whisper_amd.longform import _split_segments
+    fx = _hf_sequential()
+    tb, eot = fx["timestamp_begin"], 50257
+    assert len(fx["segments"]) >= 40
+    for c in fx["segments"]:
+        ids, seek, frames, hf = c["ids"], c["seek"], c["frames"], c["hf"]
+        ora, ora_next = wo.split_segments(ids, tb, seek, frames)
+        prod, prod_next = _split_segments(list(ids), tb, eot, seek, frames, lambda t: "x" * len(t), {})
+        assert ora_next - seek == prod_next - seek == c["hf_advance"], c["case"]
+        assert len(ora) == len(prod) == len(hf), c["case"]
+        lone_end = len(ids) >= 2 and ids[-1] >= tb and ids[-2] < tb
+        has_pair = any(a >= tb and b >= tb for a, b in zip(ids, ids[1:]))
+        for i, (o, p, h) in enumerate(zip(ora, prod, hf)):
+            np.testing.assert_allclose([o[0], o[1]], [h["start"], h["end"]], rtol=0, atol=1e-9, err_msg=c["case"])
+            np.testing.assert_allclose([p["start"], p["end"]], [h["start"], h["end"]], rtol=0, atol=1e-9, err_msg=c["case"])
+            want = h["tokens"]
+            if has_pair and not lone_end and i == len(hf) - 1:
+                assert want[-1] >= tb and want[-2] >= tb
+                want = want[:-1]                      # HF's marker copy of the closing pair's second timestamp
+            assert list(o[2]) == want, c["case"]
+            # the product drops the ids of zero-length / text-less segments (upstream, not part of HF's helper)
+            empty = o[0] == o[1] or not [t for t in want if t < eot]
+            assert p["tokens"] == ([] if empty else want), c["case"]
+
+
+def test_fallback_predicates_match_hf_need_fallback():
+    """needs_fallback / should_skip of the oracle and of the product against ``_need_fallback`` on a 2 x 3 x 3 grid of
+    (compression ratio, avg log-probability, no-speech probability) around the default thresholds 2.4 / -1.0 / 0.6.  Where
+    upstream [upstream-recall] and HF differ by design -- a repetitive but LIKELY window that looks like silence: upstream
+    cancels the fallback on the no-speech probability alone, HF also wants the log-probability below its threshold -- the
+    restatements follow upstream and the test says so."""
+    from whisper_amd.longform import _fallback_decision
+    fx = _hf_sequential()
+    diverged = 0
+    for c in fx["fallback"]:
+        cr, lp, ns = c["compression_ratio"], c["avg_logprob"], c["no_speech_prob"]
+        got_o = wo.fallback_decision(cr, lp, ns)
+        got_p = _fallback_decision(cr, lp, ns, 2.4, -1.0, 0.6)
+        assert tuple(got_o) == tuple(got_p)
+        if cr > 2.4 and lp >= -1.0 and ns > 0.6:
+            assert c["hf_needs_fallback"] and not got_o[0]            # the designed difference
+            diverged += 1
+        else:
+            assert got_o[0] == c["hf_needs_fallback"], c
+        assert got_o[1] == c["hf_should_skip"], c
+    assert diverged == 1 and len(fx["fallback"]) == 18
+    # thresholds switched off one at a time
+    assert _fallback_decision(9.0, -0.1, 0.0, None, -1.0, 0.6) == (False, False) == tuple(wo.fallback_decision(9.0, -0.1, 0.0, None, -1.0, 0.6))
+    assert _fallback_decision(1.0, -5.0, 0.9, 2.4, None, 0.6) == (False, True) == tuple(wo.fallback_decision(1.0, -5.0, 0.9, 2.4, None, 0.6))
+    assert _fallback_decision(1.0, -5.0, 0.9, 2.4, -1.0, None) == (True, False) == tuple(wo.fallback_decision(1.0, -5.0, 0.9, 2.4, -1.0, None))
+
+
+def test_avg_logprob_counts_the_eot_step_like_hf():
+    from whisper_amd.longform import _avg_logprob
+    for c in _hf_sequential()["avg_logprob"]:
+        assert abs(wo.avg_logprob(c["sum_logprob"], c["n_tokens"]) - c["hf"]) < 1e-5 * abs(c["hf"])
+        assert abs(_avg_logprob(c["sum_logprob"], c["n_tokens"]) - c["hf"]) < 1e-5 * abs(c["hf"])

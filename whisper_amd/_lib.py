@@ -36,6 +36,7 @@ PROTOTYPES = {
     "wx_set_mel_filters": (c_i32, [c_vp, c_vp]),
     "wx_set_suppress_tokens": (c_i32, [c_vp, c_vp, c_i32]),
     "wx_finalize": (c_i32, [c_vp]),
+    "wx_create_shared": (c_i32, [c_vp, ctypes.POINTER(WxConfig), ctypes.POINTER(c_vp)]),
     "wx_pcm16_to_f32": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     "wx_resample_pcm16": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "wx_mel_reset_max": (c_i32, [c_vp, c_vp, c_vp]),
@@ -44,6 +45,7 @@ PROTOTYPES = {
     "wx_log_mel_static": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
     "wx_encode": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "wx_get_encoder_output": (c_i32, [c_vp, c_i32, c_vp, c_vp]),
+    "wx_compact_windows": (c_i32, [c_vp, c_vp, c_i32, c_vp]),
     "wx_decode_greedy": (c_i32, [c_vp, c_i32, c_vp, ctypes.POINTER(WxDecodeOpts), c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_i32), c_vp]),
     "wx_decode_rows": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, ctypes.POINTER(WxDecodeOpts), ctypes.c_float, ctypes.c_uint32, c_vp, c_vp, c_vp,
                                c_vp, ctypes.POINTER(c_i32), c_vp]),

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -48,6 +49,21 @@ struct LayerW {
     void *w1_pk = nullptr, *w2_pk = nullptr, *xq_pk = nullptr, *xo_pk = nullptr;
 };
 
+// Device allocations that hold WEIGHTS (and the read-only mel tables): owned by a block that every engine built from the same
+// weights refers to (wx_create_shared), freed with the last of them.
+struct WeightBlock {
+    int device = 0;
+    std::vector<void*> allocs;
+    int64_t bytes = 0;
+    ~WeightBlock() {
+        int prev = -1;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) (void)hipSetDevice(device);
+        for (void* p : allocs) (void)hipFree(p);
+        if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    }
+};
+
 }  // namespace
 
 struct wx_engine {
@@ -57,7 +73,9 @@ struct wx_engine {
     std::map<std::string, HostTensor> staged;
     std::vector<float> mel_filters_h;
     std::vector<int32_t> suppress_h;
-    std::vector<void*> allocs;
+    std::vector<void*> allocs;                               // workspace, caches, decode state: this engine's own
+    std::shared_ptr<WeightBlock> wb;                         // weights: shared with the engines wx_create_shared made from this one
+    bool owns_weights = true;                                // false: built by wx_create_shared (wx_weight_bytes reports 0)
     int64_t weight_bytes = 0, work_bytes = 0;
 
     // dims
@@ -123,8 +141,8 @@ int dev_alloc(wx_engine* e, void** p, size_t bytes, bool weight) {
     if (bytes == 0) bytes = 16;
     hipError_t r = hipMalloc(p, bytes);
     if (r != hipSuccess) return fail(WX_ERR_NOMEM, "hipMalloc(" + std::to_string(bytes) + "): " + hipGetErrorString(r));
-    e->allocs.push_back(*p);
-    (weight ? e->weight_bytes : e->work_bytes) += (int64_t)bytes;
+    if (weight) { e->wb->allocs.push_back(*p); e->wb->bytes += (int64_t)bytes; e->weight_bytes += (int64_t)bytes; }
+    else { e->allocs.push_back(*p); e->work_bytes += (int64_t)bytes; }
     return 0;
 }
 
@@ -301,6 +319,8 @@ int wx_create(const wx_config* cfg, wx_engine** out) {
     }
     wx_engine* e = new wx_engine();
     e->cfg = c;
+    e->wb = std::make_shared<WeightBlock>();
+    e->wb->device = c.device;
     DeviceScope dev_scope(e);
     e->dt = c.precision == WX_PREC_BF16 ? DT_BF16 : DT_F32;
     e->d = c.n_audio_state; e->H = c.n_audio_head; e->dt_ = c.n_text_state; e->Ht = c.n_text_head;
@@ -331,6 +351,7 @@ void wx_destroy(wx_engine* e) {
     if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
     for (hipEvent_t ev : e->prof_events) (void)hipEventDestroy(ev);
     for (void* p : e->allocs) (void)hipFree(p);
+    e->wb.reset();                                           // frees the weights with the last engine that uses them
     if (e->h_pinned) (void)hipHostFree(e->h_pinned);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
@@ -372,16 +393,13 @@ int wx_set_suppress_tokens(wx_engine* e, const int32_t* h_ids, int32_t n) {
     return WX_OK;
 }
 
-int wx_finalize(wx_engine* e) {
-    if (!e) return fail(WX_ERR_INVALID, "null engine");
-    if (e->finalized) return fail(WX_ERR_STATE, "engine already finalized");
-    if (e->mel_filters_h.empty()) return fail(WX_ERR_STATE, "mel filters not set");
-    DeviceScope dev_scope(e);
+}  // extern "C"
+
+// weights and read-only tables -> the engine's weight block (caller holds a DeviceScope)
+static int build_weights(wx_engine* e) {
     const wx_config& c = e->cfg;
-    const int d = e->d, B = c.max_batch, T = e->T;
-    const size_t es = dtype_size(e->dt);
+    const int d = e->d, T = e->T;
     int r;
-    // ---- weights ----
     if ((r = build_conv(e, "encoder.conv1", d, c.n_mels, e->c_pad, &e->conv1_w, &e->conv1_b))) return r;
     if ((r = build_conv(e, "encoder.conv2", d, d, d, &e->conv2_w, &e->conv2_b))) return r;
     {
@@ -490,15 +508,23 @@ int wx_finalize(wx_engine* e) {
         e->mel.n_pack = (int)pack.size();
         e->mel.window = w; e->mel.cs = t; e->mel.filters = f; e->mel.frange = (const int32_t*)fp; e->mel.n_mels = c.n_mels;
     }
-    {
+    return 0;
+}
+
+// workspace, caches and decode state of ONE engine (its own even when the weights are shared; caller holds a DeviceScope)
+static int build_workspace(wx_engine* e) {
+    const wx_config& c = e->cfg;
+    const int d = e->d, B = c.max_batch, T = e->T;
+    const size_t es = dtype_size(e->dt);
+    int r;
+    {   // the suppress mask can be replaced per engine after wx_finalize (wx_set_suppress_tokens): never shared
         std::vector<uint8_t> m(e->vocab_pad, 0);       // padded: the sampler reads the mask 4 bytes at a time
         for (int id : e->suppress_h) m[id] = 1;
         void* p;
-        if ((r = dev_alloc(e, &p, m.size(), true))) return r;
+        if ((r = dev_alloc(e, &p, m.size(), false))) return r;
         HIP_TRY(hipMemcpy(p, m.data(), m.size(), hipMemcpyHostToDevice));
         e->suppress = (uint8_t*)p;
     }
-    // ---- workspace ----
     {
         const int passes = (B + DG_MAX_ROWS - 1) / DG_MAX_ROWS;
         e->pass_rows = passes <= 1 ? B : (((B + passes - 1) / passes + 15) / 16) * 16;
@@ -585,9 +611,62 @@ int wx_finalize(wx_engine* e) {
     if ((r = A((void**)&e->rs_taps, (size_t)RS_MAX_TAPS * 4))) return r;
     HIP_TRY(hipHostMalloc((void**)&e->h_pinned, 64));
     HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
+extern "C" {
+
+int wx_finalize(wx_engine* e) {
+    if (!e) return fail(WX_ERR_INVALID, "null engine");
+    if (e->finalized) return fail(WX_ERR_STATE, "engine already finalized");
+    if (e->mel_filters_h.empty()) return fail(WX_ERR_STATE, "mel filters not set");
+    DeviceScope dev_scope(e);
+    int r;
+    if ((r = build_weights(e))) return r;
+    if ((r = build_workspace(e))) return r;
     e->finalized = true;
     return WX_OK;
 }
+
+// A second engine on the SAME weights: the parent's weight pointers are copied, the weight block is shared (freed with the last
+// engine that refers to it), workspace / caches / decode state / graph are the new engine's own.
+int wx_create_shared(const wx_engine* parent, const wx_config* cfg, wx_engine** out) {
+    if (!parent || !cfg || !out) return fail(WX_ERR_INVALID, "null argument");
+    if (!parent->finalized) return fail(WX_ERR_STATE, "the parent engine is not finalized");
+    const wx_config &c = *cfg, &pc = parent->cfg;
+    if (c.n_mels != pc.n_mels || c.n_audio_ctx != pc.n_audio_ctx || c.n_audio_state != pc.n_audio_state || c.n_audio_head != pc.n_audio_head ||
+        c.n_audio_layer != pc.n_audio_layer || c.n_vocab != pc.n_vocab || c.n_text_ctx != pc.n_text_ctx || c.n_text_state != pc.n_text_state ||
+        c.n_text_head != pc.n_text_head || c.n_text_layer != pc.n_text_layer || c.precision != pc.precision || c.device != pc.device)
+        return fail(WX_ERR_INVALID, "wx_create_shared: model dimensions, precision and device must be the parent's");
+    if (c.max_batch <= 0) return fail(WX_ERR_INVALID, "bad dimensions");
+    wx_engine* e = nullptr;
+    int r = wx_create(cfg, &e);
+    if (r) return r;
+    if (e->xattn != parent->xattn) {
+        wx_destroy(e);
+        return fail(WX_ERR_INVALID, "wx_create_shared: this max_batch selects the other cross-attention form (its weight layouts are not in the parent)");
+    }
+    DeviceScope dev_scope(e);
+    e->wb = parent->wb;
+    e->owns_weights = false;
+    e->conv1_w = parent->conv1_w; e->conv2_w = parent->conv2_w; e->conv1_b = parent->conv1_b; e->conv2_b = parent->conv2_b; e->enc_pos = parent->enc_pos;
+    e->enc = parent->enc; e->dec = parent->dec;
+    e->lnpost_g = parent->lnpost_g; e->lnpost_b = parent->lnpost_b; e->declnf_g = parent->declnf_g; e->declnf_b = parent->declnf_b;
+    e->tok_emb = parent->tok_emb; e->dec_pos = parent->dec_pos; e->tok_emb_pk = parent->tok_emb_pk;
+    e->mel = parent->mel;
+    e->suppress_h = parent->suppress_h;
+    const int64_t shared_bytes = e->wb->bytes;
+    if ((r = build_workspace(e))) { wx_destroy(e); return r; }
+    if (e->wb->bytes != shared_bytes) { wx_destroy(e); return fail(WX_ERR_STATE, "wx_create_shared: the workspace allocated into the shared weight block"); }
+    e->weight_bytes = 0;
+    e->finalized = true;
+    *out = e;
+    return WX_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
 
 int wx_pcm16_to_f32(wx_engine* e, const int16_t* d_pcm16, int64_t n, float* d_out, void* stream) {
     if (!e || !d_pcm16 || !d_out || n < 0) return fail(WX_ERR_INVALID, "bad argument");
@@ -779,6 +858,35 @@ int wx_get_encoder_output(wx_engine* e, int32_t B, float* d_out, void* stream) {
     DeviceScope dev_scope(e);
     if (!d_out || B <= 0 || B > e->encoded_B) return fail(WX_ERR_INVALID, "no encoder output for that batch");
     WX_TRY(launch_to_f32(e->enc_out, e->dt, d_out, (int64_t)B * e->T * e->d, (hipStream_t)stream));
+    return WX_OK;
+}
+
+int wx_compact_windows(wx_engine* e, const int32_t* h_src, int32_t n, void* stream) {
+    if (!e || !e->finalized) return fail(WX_ERR_STATE, "engine not finalized");
+    DeviceScope dev_scope(e);
+    if (!h_src || n <= 0 || n > e->encoded_B) return fail(WX_ERR_INVALID, "bad compaction arguments (1 <= n <= windows of the last wx_encode)");
+    for (int i = 0; i < n; ++i)
+        if (h_src[i] < i || h_src[i] >= e->encoded_B || (i > 0 && h_src[i] <= h_src[i - 1]))
+            return fail(WX_ERR_INVALID, "h_src must be strictly ascending slots of the last wx_encode");
+    hipStream_t st = (hipStream_t)stream;
+    const int d = e->d, T = e->T;
+    const size_t es = dtype_size(e->dt);
+    const bool kv_valid = e->crossK && (!e->xattn || e->cross_kv_B >= e->encoded_B);
+    const size_t enc_slot = (size_t)T * d * es, frag_slot = (size_t)e->x_nt16 * 16 * d * 2, kv_slot = (size_t)e->Ht * T * HEAD_DIM * es;
+    const size_t cross_layer = (size_t)e->cfg.max_batch * e->Ht * T * HEAD_DIM * es;
+    for (int i = 0; i < n; ++i) {          // ascending and h_src[i] >= i: a slot is read before anything overwrites it
+        const int sidx = h_src[i];
+        if (sidx == i) continue;
+        HIP_TRY(hipMemcpyAsync((char*)e->enc_out + i * enc_slot, (char*)e->enc_out + sidx * enc_slot, enc_slot, hipMemcpyDeviceToDevice, st));
+        if (e->xattn) HIP_TRY(hipMemcpyAsync((char*)e->enc_frag + i * frag_slot, (char*)e->enc_frag + sidx * frag_slot, frag_slot, hipMemcpyDeviceToDevice, st));
+        if (kv_valid)
+            for (int l = 0; l < e->cfg.n_text_layer; ++l) {
+                HIP_TRY(hipMemcpyAsync((char*)e->crossK + l * cross_layer + i * kv_slot, (char*)e->crossK + l * cross_layer + sidx * kv_slot, kv_slot, hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipMemcpyAsync((char*)e->crossV + l * cross_layer + i * kv_slot, (char*)e->crossV + l * cross_layer + sidx * kv_slot, kv_slot, hipMemcpyDeviceToDevice, st));
+            }
+    }
+    e->cross_kv_B = kv_valid ? n : 0;
+    e->encoded_B = n;
     return WX_OK;
 }
 
@@ -1328,7 +1436,7 @@ int wx_decoder_logits(wx_engine* e, int32_t B, const int32_t* d_tokens, int32_t 
     return WX_OK;
 }
 
-int64_t wx_weight_bytes(wx_engine* e) { return e ? e->weight_bytes : 0; }
+int64_t wx_weight_bytes(wx_engine* e) { return e && e->owns_weights ? e->weight_bytes : 0; }
 int64_t wx_workspace_bytes(wx_engine* e) { return e ? e->work_bytes : 0; }
 int32_t wx_cross_attention_form(wx_engine* e) { return e && e->xattn ? 1 : 0; }
 int32_t wx_cross_key_splits(wx_engine* e) { return !e || !e->finalized ? 0 : e->xattn ? e->x_split : cross_attn_key_split(e); }

@@ -35,11 +35,13 @@ def _ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
 class WhisperEngine:
     def __init__(self, dims: ModelDims, state_dict: Dict[str, torch.Tensor], precision: str = "bf16",
                  max_batch: int = 8, device: int = 0, suppress_ids: Optional[Sequence[int]] = None,
-                 mel_filters: Optional[np.ndarray] = None, n_lanes: int = 1):
+                 mel_filters: Optional[np.ndarray] = None, n_lanes: int = 1, share_weights_with: Optional["WhisperEngine"] = None):
         """``mel_filters``: optional ``[n_mels, 201]`` float32 filterbank (e.g. the array of upstream's
         ``assets/mel_filters.npz``); default: the Slaney bank computed by ``audio.slaney_mel_filterbank``.
         ``n_lanes``: how many engines will share this GPU at the same time (whisper_amd/lanes.py); sizes the grid of the
-        decoder's cross-attention stream (wx_config.n_lanes)."""
+        decoder's cross-attention stream (wx_config.n_lanes).
+        ``share_weights_with``: an engine of the same model, precision and device whose device weights this one uses instead
+        of uploading its own (``wx_create_shared``; ``state_dict`` is then ignored and may be None) -- see ``replica()``."""
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
         if not torch.cuda.is_available():
@@ -59,6 +61,16 @@ class WhisperEngine:
             tok_timestamp_begin=t.timestamp_begin, tok_blank=t.blank, n_lanes=int(n_lanes))
         self.n_lanes = int(n_lanes)
         handle = ctypes.c_void_p()
+        if share_weights_with is not None:
+            p = share_weights_with
+            if (p.dims, p.precision, p.device) != (dims, precision, self.device) or not p.handle:
+                raise ValueError("share_weights_with: a live engine of the same model, precision and device is needed")
+            _lib.check(self.lib.wx_create_shared(p.handle, ctypes.byref(cfg), ctypes.byref(handle)), "wx_create_shared")
+            self.handle = handle
+            self.suppress_ids = list(p.suppress_ids)
+            if suppress_ids is not None:
+                self.set_suppress_ids(suppress_ids)
+            return
         _lib.check(self.lib.wx_create(ctypes.byref(cfg), ctypes.byref(handle)), "wx_create")
         self.handle = handle
         try:
@@ -79,6 +91,17 @@ class WhisperEngine:
         except Exception:
             self.close()
             raise
+
+    def replica(self, max_batch: Optional[int] = None, n_lanes: Optional[int] = None) -> "WhisperEngine":
+        """Another engine on this engine's device weights (own workspace, caches, decode graph): what a lane of
+        whisper_amd/lanes.py runs on.  The weights stay resident until the last engine that uses them is closed."""
+        return WhisperEngine(self.dims, None, precision=self.precision, max_batch=self.max_batch if max_batch is None else max_batch,
+                             device=self.device, n_lanes=self.n_lanes if n_lanes is None else n_lanes, share_weights_with=self)
+
+    def set_suppress_ids(self, ids: Sequence[int]) -> None:
+        self.suppress_ids = [int(i) for i in ids]
+        sup = np.asarray(self.suppress_ids, np.int32)
+        _lib.check(self.lib.wx_set_suppress_tokens(self.handle, sup.ctypes.data_as(ctypes.c_void_p), len(sup)), "wx_set_suppress_tokens")
 
     # -- lifetime ---------------------------------------------------------------------------------------
     def close(self) -> None:
@@ -205,6 +228,12 @@ class WhisperEngine:
         out = torch.empty((B, self.dims.n_audio_ctx, self.dims.n_audio_state), dtype=torch.float32, device=self.torch_device)
         _lib.check(self.lib.wx_get_encoder_output(self.handle, B, _ptr(out), self._stream()), "wx_get_encoder_output")
         return out
+
+    def compact_windows(self, keep: Sequence[int]) -> None:
+        """Keep the windows ``keep`` (strictly ascending slots of the last encode) as slots 0..len(keep)-1, so that the next
+        decode call runs on them alone: upstream's temperature fallback re-decodes only the windows that failed its checks."""
+        src = np.asarray([int(k) for k in keep], np.int32)
+        _lib.check(self.lib.wx_compact_windows(self.handle, src.ctypes.data_as(ctypes.c_void_p), len(src), self._stream()), "wx_compact_windows")
 
     # -- decoder ------------------------------------------------------------------------------------------
     def decode_greedy(self, B: int, prompt: Sequence[int], max_new_tokens: int = 0, without_timestamps: bool = True,

@@ -6,11 +6,15 @@ stream per layer, and the encoder runs alone in front of it.  A second, independ
 run beside the other batch's stream, its encoder beside the other's decode loop.  Measured on one MI355X, large-v3 bf16, 64
 windows per batch, 224 tokens: 1053 ms per batch with 1 lane, 816 with 2, 742 with 3, 705 with 4 (1823 -> 2723 audio-s/s; each
 engine sizes its cross-attention grid for its share of the GPU, wx_config.n_lanes), no further gain at 6 or 8 (the runtime maps
-streams onto 4 hardware queues).  The batches
-stay what they were (same kernels, same max_batch, same key split), so a window's ids do not depend on the lane it ran on
-(tests/test_gpu_api.py::test_lanes_decode_the_same_ids).
+streams onto 4 hardware queues).  Every lane runs the
+same engine configuration (same kernels, same max_batch, same n_lanes and therefore the same key split of the cross-attention
+stream), so a window's ids do not depend on the lane it ran on (tests/test_gpu_api.py::test_lanes_decode_the_same_ids).  The
+number of lanes itself is part of that configuration: it sets the key split, and each split's partial context is rounded to bf16
+before the splits are combined -- bf16 results of configure(lanes=4) differ from lanes=1 by rounding noise (measured 0.09 noise
+floors on the logits at large-v3, tests/test_gpu_configs.py), fp32 results do not change at all.
 
-What it costs: one more copy of the weights and of the workspace per lane (large-v3 bf16, max_batch 64: 4.7 + 8 GB of 288).
+What it costs: one more workspace per lane (large-v3 bf16, max_batch 64: 8 GB of 288).  The weights exist once: the lanes after
+the first are made with ``WhisperEngine.replica()`` (``wx_create_shared``), which shares the first engine's device weights.
 
 The reference has no counterpart: its model is one global object behind an asyncio lock-free call
 (ref:app/transcription/speech_recognition.py:20-26,55), one file at a time.  Independent 30 s windows are what
@@ -18,11 +22,15 @@ makes batches, and therefore lanes, possible.
 """
 from __future__ import annotations
 
+import logging
 import queue
 import threading
 from typing import Callable, Dict, List, Optional, Sequence
 
 import torch
+
+
+log = logging.getLogger(__name__)
 
 
 class _Lane:
@@ -84,12 +92,23 @@ class EngineLanes:
         self._next = 0
 
     @classmethod
-    def create(cls, make_engine: Callable[[int], object], n_lanes: int) -> "EngineLanes":
-        """``make_engine(n_lanes)`` builds one replica; it should pass ``n_lanes`` on to ``WhisperEngine`` so that the engine
-        sizes its cross-attention grid for its share of the GPU."""
+    def create(cls, make_engine: Callable[[int], object], n_lanes: int, share_weights: bool = True) -> "EngineLanes":
+        """``make_engine(n_lanes)`` builds the first engine; it should pass ``n_lanes`` on to ``WhisperEngine`` so that the
+        engine sizes its cross-attention grid for its share of the GPU.  The other lanes are ``replica()``s of it -- same
+        configuration, the same device weights (``wx_create_shared``) -- unless ``share_weights`` is False or the engine has
+        no ``replica`` (a stand-in), in which case ``make_engine`` is called once per lane."""
         if n_lanes < 1:
             raise ValueError("n_lanes must be >= 1")
-        return cls([make_engine(n_lanes) for _ in range(n_lanes)])
+        first = make_engine(n_lanes)
+        engines = [first]
+        try:
+            for _ in range(n_lanes - 1):
+                engines.append(first.replica() if share_weights and hasattr(first, "replica") else make_engine(n_lanes))
+        except BaseException:
+            for e in engines:
+                e.close()
+            raise
+        return cls(engines)
 
     @property
     def n_lanes(self) -> int:
@@ -116,7 +135,15 @@ class EngineLanes:
     def map(self, fn: Callable, items: Sequence) -> List:
         """``[fn(engine, item) for item in items]``, item i on lane i mod n_lanes, results in order."""
         pend = [self.submit(fn, item, lane=i % len(self._lanes)) for i, item in enumerate(items)]
-        return [p.result() for p in pend]
+        out, first_error = [], None
+        for p in pend:                                     # every job has ended before an error leaves this function: the
+            try:                                           # others may still be reading what the caller passed in
+                out.append(p.result())
+            except BaseException as exc:
+                first_error = first_error or exc
+        if first_error is not None:
+            raise first_error
+        return out
 
     def transcribe_mel(self, mel: torch.Tensor, n_content_frames: int, window_lo: int, window_hi: int,
                        prompt: Sequence[int], beam_size: Optional[int] = None, patience: float = 1.0, **decode_kw) -> Dict[str, object]:
@@ -142,7 +169,14 @@ class EngineLanes:
         for ln in self._lanes:
             ln.jobs.put(None)
         for ln in self._lanes:
+            waited = 0
             ln.thread.join(timeout=60)
+            while ln.thread.is_alive() and waited < 10:    # a long decode or a first graph capture is still running: destroying
+                log.warning("lane %d is still busy; waiting for its job before its engine is destroyed", ln.index)
+                ln.thread.join(timeout=60); waited += 1    # the engine under it would free memory its kernels are using
+            if ln.thread.is_alive():
+                log.error("lane %d did not finish; its engine is left alive (leaked) rather than destroyed under a running job", ln.index)
+                continue
             ln.engine.close()
         self._lanes = []
 

@@ -53,42 +53,61 @@ class _FileState:
         return self.seek >= self.content_frames
 
 
-def _split_segments(tokens: List[int], tb: int, eot: int, seek: int, segment_size: int, decode_text, meta: Dict[str, object]):
-    """ids of one window -> (segments, next seek)."""
-    time_offset = seek * HOP_LENGTH / SAMPLE_RATE
-    segment_duration = segment_size * HOP_LENGTH / SAMPLE_RATE
+def _avg_logprob(sum_logprob: float, n_tokens: int) -> float:
+    """upstream DecodingResult.avg_logprob: the EOT step counts in the length"""
+    return float(sum_logprob) / (int(n_tokens) + 1)
 
-    def new_segment(start, end, toks):
-        sg = {"seek": seek, "start": start, "end": end, "tokens": list(toks), "text": decode_text([t for t in toks if t < eot])}
-        sg.update(meta)
-        return sg
-    is_ts = [t >= tb for t in tokens]
-    single_timestamp_ending = is_ts[-2:] == [False, True]
-    consecutive = [i + 1 for i in range(len(tokens) - 1) if is_ts[i] and is_ts[i + 1]]
+
+def _fallback_decision(cr: float, avg_logprob: float, no_speech_prob: float, cr_threshold: Optional[float],
+                       logprob_threshold: Optional[float], no_speech_threshold: Optional[float]):
+    """``(needs_fallback, should_skip)`` for one decoded window: upstream's ``decode_with_fallback`` test (too repetitive or too
+    unlikely, unless the window looks like silence) and ``transcribe``'s no-speech skip (silence, unless the text is likely
+    after all).  tests/golden/hf_sequential.json pins both against transformers' ``_need_fallback`` and records the two
+    corners where upstream and transformers differ."""
+    silent = no_speech_threshold is not None and no_speech_prob > no_speech_threshold
+    repetitive = cr_threshold is not None and cr > cr_threshold
+    unlikely = logprob_threshold is not None and avg_logprob < logprob_threshold
+    likely = logprob_threshold is not None and avg_logprob > logprob_threshold
+    return (repetitive or unlikely) and not silent, silent and not likely
+
+
+def _cut_at_timestamp_pairs(tokens: Sequence[int], tb: int, seek: int, segment_size: int):
+    """ids of one window -> ``([(start s, end s, lo, hi)], next seek)``: index ranges ``[lo, hi)`` of the segments and where the
+    next window starts.  A segment ends after the first timestamp of every <|t|><|t|> pair; ids after the last pair are
+    dropped and decoded again from that timestamp, unless the ids end in a lone timestamp (then they are the last segment
+    and the whole window is consumed); without any pair the window is one segment."""
+    ids = np.asarray(list(tokens), dtype=np.int64)
+    n = ids.size
+    t0 = seek * HOP_LENGTH / SAMPLE_RATE
+    is_ts = ids >= tb
+    ends = (np.flatnonzero(is_ts[:-1] & is_ts[1:]) + 1).tolist() if n >= 2 else []       # index after the first timestamp of a pair
+    lone_end = n >= 2 and bool(is_ts[-1]) and not bool(is_ts[-2])
+    if not ends:
+        stamps = ids[is_ts]
+        length = segment_size * HOP_LENGTH / SAMPLE_RATE
+        if stamps.size and int(stamps[-1]) != tb:
+            length = (int(stamps[-1]) - tb) * TIME_PRECISION
+        return [(t0, t0 + length, 0, n)], seek + segment_size
+    if lone_end:
+        ends.append(n)
+    bounds = list(zip([0] + ends[:-1], ends))
+    spans = [(t0 + (int(ids[lo]) - tb) * TIME_PRECISION, t0 + (int(ids[hi - 1]) - tb) * TIME_PRECISION, lo, hi) for lo, hi in bounds]
+    advance = segment_size if lone_end else (int(ids[ends[-1] - 1]) - tb) * INPUT_STRIDE
+    return spans, seek + advance
+
+
+def _split_segments(tokens: List[int], tb: int, eot: int, seek: int, segment_size: int, decode_text, meta: Dict[str, object]):
+    """ids of one window -> (segments, next seek); zero-length and text-less segments keep their times and lose their ids
+    (upstream drops them from the prompt carry-over)."""
+    spans, nxt = _cut_at_timestamp_pairs(tokens, tb, seek, segment_size)
     out = []
-    if consecutive:
-        slices = list(consecutive)
-        if single_timestamp_ending:
-            slices.append(len(tokens))
-        last_slice = 0
-        for cur in slices:
-            sl = tokens[last_slice:cur]
-            out.append(new_segment(time_offset + (sl[0] - tb) * TIME_PRECISION, time_offset + (sl[-1] - tb) * TIME_PRECISION, sl))
-            last_slice = cur
-        if single_timestamp_ending:
-            nxt = seek + segment_size          # a single timestamp at the end: no speech after it
-        else:
-            nxt = seek + (tokens[last_slice - 1] - tb) * INPUT_STRIDE
-    else:
-        duration = segment_duration
-        ts = [t for t in tokens if t >= tb]
-        if ts and ts[-1] != tb:
-            duration = (ts[-1] - tb) * TIME_PRECISION
-        out.append(new_segment(time_offset, time_offset + duration, tokens))
-        nxt = seek + segment_size
-    for sg in out:
-        if sg["start"] == sg["end"] or sg["text"].strip() == "":
+    for start, end, lo, hi in spans:
+        toks = list(tokens[lo:hi])
+        sg = {"seek": seek, "start": start, "end": end, "tokens": toks, "text": decode_text([t for t in toks if t < eot])}
+        sg.update(meta)
+        if start == end or sg["text"].strip() == "":
             sg["text"] = ""; sg["tokens"] = []
+        out.append(sg)
     return out, nxt
 
 
@@ -133,23 +152,25 @@ def transcribe_sequential(engine, audios: Sequence, decode_text: Callable[[Seque
                    for s in active]
         result: List[Optional[Dict[str, object]]] = [None] * B
         pending = list(range(B))
+        slots = list(range(B))                 # file b of `active` whose window sits in engine slot j
+        can_compact = hasattr(engine, "compact_windows")
         for attempt, t in enumerate(temperatures):
-            r = engine.decode_rows(prompts, temperature=float(t), seed=(seed * 1000003 + active[0].windows * 101 + attempt) & 0x7FFFFFFF,
+            if attempt > 0 and can_compact and len(pending) < len(slots):
+                # upstream re-decodes ONLY the windows that failed: move their encoder results to the front and decode those rows
+                engine.compact_windows([slots.index(b) for b in pending])
+                slots = list(pending)
+            r = engine.decode_rows([prompts[b] for b in slots], temperature=float(t),
+                                   seed=(seed * 1000003 + active[0].windows * 101 + attempt) & 0x7FFFFFFF,
                                    max_new_tokens=max_new_tokens, without_timestamps=False, use_graph=use_graph)
             still = []
             for b in pending:
-                toks = r["tokens"][b]
-                avg_logprob = r["sum_logprobs"][b] / (len(toks) + 1)
+                j = slots.index(b)
+                toks = r["tokens"][j]
+                avg_logprob = _avg_logprob(r["sum_logprobs"][j], len(toks))
                 text = decode_text([x for x in toks if x < tok.eot]).strip()
                 cr = compression_ratio(text) if text else 0.0
-                nsp = r["no_speech_probs"][b]
-                needs_fallback = False
-                if compression_ratio_threshold is not None and cr > compression_ratio_threshold:
-                    needs_fallback = True
-                if logprob_threshold is not None and avg_logprob < logprob_threshold:
-                    needs_fallback = True
-                if no_speech_threshold is not None and nsp > no_speech_threshold:
-                    needs_fallback = False
+                nsp = r["no_speech_probs"][j]
+                needs_fallback, _ = _fallback_decision(cr, avg_logprob, nsp, compression_ratio_threshold, logprob_threshold, no_speech_threshold)
                 result[b] = {"tokens": toks, "temperature": float(t), "avg_logprob": avg_logprob, "compression_ratio": cr,
                              "no_speech_prob": nsp, "needs_fallback": needs_fallback}
                 if needs_fallback:
@@ -160,13 +181,10 @@ def transcribe_sequential(engine, audios: Sequence, decode_text: Callable[[Seque
         for b, s in enumerate(active):
             res = result[b]
             s.windows += 1
-            if no_speech_threshold is not None:
-                should_skip = res["no_speech_prob"] > no_speech_threshold
-                if logprob_threshold is not None and res["avg_logprob"] > logprob_threshold:
-                    should_skip = False
-                if should_skip:
-                    s.seek += sizes[b]
-                    continue
+            if _fallback_decision(res["compression_ratio"], res["avg_logprob"], res["no_speech_prob"], compression_ratio_threshold,
+                                  logprob_threshold, no_speech_threshold)[1]:
+                s.seek += sizes[b]                     # looks like silence: nothing is emitted for this window
+                continue
             meta = {k: res[k] for k in ("temperature", "avg_logprob", "compression_ratio", "no_speech_prob", "needs_fallback")}
             segs, nxt = _split_segments(res["tokens"], tok.timestamp_begin, tok.eot, s.seek, sizes[b], decode_text, meta)
             s.segments.extend(segs)
