@@ -153,21 +153,57 @@ def launch_ranks(n: int) -> int:
     import subprocess
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    procs = []
+        port = sk.getsockname()[1]          # (released before the ranks bind it: a clash shows up as a failed rank, reported below)
+    import tempfile
+    import threading
+    procs, logs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        log = tempfile.TemporaryFile(mode="w+")           # per-rank stderr (and stdout of ranks > 0): its tail goes into the failure message
+        logs.append(log)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0 or "")
+                                      stdout=subprocess.PIPE if r == 0 else log, stderr=log, text=True))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + float(os.environ.get("BENCH_LAUNCH_TIMEOUT_S", "3000"))
+    failed = None
+    while True:                                           # watch EVERY rank: one that dies leaves the others in a collective forever
+        rcs = [p.poll() for p in procs]
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad or all(rc == 0 for rc in rcs):
+            failed = bad
+            break
+        if time.monotonic() > deadline:
+            failed = [(r, "timeout") for r, rc in enumerate(rcs) if rc is None]
+            break
+        time.sleep(0.2)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    reader.join(timeout=10)
+    sys.stdout.write("".join(out0))
     sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        print(f"bench.py: ranks failed: {bad}", file=sys.stderr)
+    if failed:
+        print(f"bench.py: ranks failed: {failed}", file=sys.stderr)
+        for r, _ in failed:
+            logs[r].seek(0)
+            tail = logs[r].read()[-2000:]
+            if tail.strip():
+                print(f"--- rank {r} (tail) ---\n{tail}", file=sys.stderr)
         return 1
+    for r, log in enumerate(logs):                        # a clean run: pass the ranks' stderr on
+        log.seek(0)
+        txt = log.read()
+        if txt.strip():
+            sys.stderr.write(txt)
     return 0
 
 

@@ -148,6 +148,15 @@ int wx_encode(wx_engine* e, const float* d_mel, int64_t win_stride, int64_t row_
               int32_t B, void* stream);
 int wx_get_encoder_output(wx_engine* e, int32_t B, float* d_out, void* stream);
 
+/* bf16 engines with max_batch >= 32 run greedy / sampling decodes on the encoder output and own NO per-layer cross K/V cache;
+ * beam search at width > 1 needs one and allocates it inside its first call (2 x max_batch x n_text_layer x 1500 x d x 2 bytes:
+ * 15.7 GB at large-v3 x 64 rows), where an out-of-memory failure would surface mid-request and the allocation stalls other
+ * engines on the device.  Call this once after wx_finalize / wx_create_shared when beam search is expected (upstream
+ * DecodingOptions.beam_size; the reference's own call never sets it, ref:speech_recognition.py:48-52): the cache is allocated
+ * now (WX_ERR_NOMEM now), never freed before wx_destroy, and projected lazily as before.  A no-op on engines that own the
+ * cache already. */
+int wx_reserve_cross_kv(wx_engine* e);
+
 /* serves upstream's decode_with_fallback (Whisper.transcribe inside ref:speech_recognition.py:55 re-decodes ONLY the windows whose
  * compression-ratio / log-probability checks failed): keep n windows of the last wx_encode -- slot i takes the encoder results of
  * slot h_src[i]; h_src strictly ascending, i <= h_src[i] < windows of the last wx_encode -- so that the next decode call runs

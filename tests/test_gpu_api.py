@@ -592,6 +592,41 @@ def test_replicas_share_one_copy_of_the_weights():
         parent.close()
 
 
+def test_reserve_cross_kv_before_the_first_beam_call():
+    """wx_reserve_cross_kv: an encoder-output engine (bf16, max_batch >= 32) allocates its cross K/V cache at once instead of
+    inside its first beam-search call; beam search then gives what it gives without the reservation, and the call is a no-op on
+    engines that own the cache already."""
+    from whisper_amd.engine import WhisperEngine
+    dims = ck.dims_for("micro")
+    sd = ck.synthetic_state_dict(dims, seed=0, eot_boost=3.0)
+    a = WhisperEngine(dims, sd, precision="bf16", max_batch=32)
+    b = a.replica()
+    try:
+        assert a.cross_form == "encoder_output"
+        w0 = b.workspace_bytes
+        b.reserve_cross_kv()
+        grown = b.workspace_bytes - w0
+        assert grown == 2 * 32 * dims.n_text_layer * 1500 * dims.n_text_state * 2
+        b.reserve_cross_kv()
+        assert b.workspace_bytes - w0 == grown                       # second call: nothing more
+        mels = _mels(dims, range(3))
+        init = a.initial_tokens(0)
+        a.encode_windows(mels); b.encode_windows(mels)
+        ra = a.decode_beam(3, init, beam_size=5, max_new_tokens=8)
+        assert a.workspace_bytes - w0 == grown                       # the lazy path allocated the same cache inside the call
+        rb = b.decode_beam(3, init, beam_size=5, max_new_tokens=8)
+        assert ra["tokens"] == rb["tokens"] and ra["sum_logprobs"] == rb["sum_logprobs"]
+        f = WhisperEngine(dims, sd, precision="fp32", max_batch=2)
+        try:
+            w1 = f.workspace_bytes
+            f.reserve_cross_kv()
+            assert f.workspace_bytes == w1
+        finally:
+            f.close()
+    finally:
+        a.close(); b.close()
+
+
 @pytest.mark.parametrize("precision,xattn", [("fp32", False), ("bf16", False), ("bf16", True)])
 def test_compact_windows_then_decode_only_those(precision, xattn):
     """wx_compact_windows: after keeping windows (1, 3) of four, a 2-row decode gives exactly the ids, log-probabilities and

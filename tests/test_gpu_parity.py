@@ -200,6 +200,44 @@ def test_cross_attention_stream_at_few_key_splits_bf16(models, name, gain, split
     assert torch.equal(eng.decode_greedy(1, init, max_new_tokens=16)["tokens"].cpu()[0], a[2])
 
 
+@pytest.mark.parametrize("name,split", [("micro", 1), ("tiny", 2), ("small1", 3), ("large1", 1), ("large1", 4)])
+def test_stream_kernels_with_and_without_the_lds_image_are_bit_identical(monkeypatch, name, split):
+    """Round 3's E-stream kernel (tile transposed by the matrix pipe from the registers the score product used, DMA staging, no
+    LDS image) against round 2's (WX_XATTN_IMAGE=1: the tile through an LDS image and transposed LDS reads): same products in
+    the same order, so logits are BIT-identical -- at every model width class (d = 128, 384, 768, 1280: 1, 3, 3 and 5 k-steps per
+    wave, 4 or 8 waves holding E, one or two query tiles with the four heads past 16 packed into shared accumulators)."""
+    import dataclasses
+    from whisper_amd.engine import WhisperEngine
+    if name == "small1":
+        dims = dataclasses.replace(ck.dims_for("small"), n_audio_layer=1, n_text_layer=1)
+    elif name == "large1":
+        dims = dataclasses.replace(ck.dims_for("large-v3"), n_audio_layer=1, n_text_layer=2)
+    else:
+        dims = ck.dims_for(name)
+    sd = ck.synthetic_state_dict(dims, seed=0, eot_boost=3.0)
+    monkeypatch.setenv("WX_XATTN", "1")
+    monkeypatch.setenv("WX_XATTN_SPLIT", str(split))
+    eng = WhisperEngine(dims, sd, precision="bf16", max_batch=3)
+    try:
+        assert eng.cross_form == "encoder_output" and eng.cross_key_splits == split
+        mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(s), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000] for s in (0, 1, 2)])
+        tok = eng.tok
+        toks = torch.tensor([[tok.sot, tok.lang(0), tok.transcribe, tok.no_timestamps, 100, 2000, 31337]] * 3)
+        eng.encode_windows(mels)
+        new = eng.decoder_logits(toks).cpu()
+        monkeypatch.setenv("WX_XATTN_IMAGE", "1")
+        old = eng.decoder_logits(toks).cpu()
+        monkeypatch.delenv("WX_XATTN_IMAGE")
+        assert torch.isfinite(new).all() and torch.equal(new, old)
+        init = wo.initial_tokens(tok, 0)
+        a = eng.decode_greedy(3, init, max_new_tokens=10, use_graph=False)
+        monkeypatch.setenv("WX_XATTN_IMAGE", "1")
+        b = eng.decode_greedy(3, init, max_new_tokens=10, use_graph=False)
+        assert torch.equal(a["tokens"], b["tokens"]) and torch.equal(a["sum_logprobs"], b["sum_logprobs"])
+    finally:
+        eng.close()
+
+
 def test_encoder_parity_256_tiles_bf16(models):
     """3 windows of a 256-wide model: M = 4500 rows (a ragged last tile) takes the 256x256 LDS-DMA GEMM kernel; the decoder
     runs its split-K GEMMs at K = 256 / 1024."""

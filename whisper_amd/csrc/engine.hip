@@ -765,9 +765,9 @@ static int project_cross_kv(wx_engine* e, int B, hipStream_t st) {
     const size_t es = dtype_size(dtp);
     const size_t cross_layer = (size_t)e->cfg.max_batch * e->Ht * T * HEAD_DIM;
     if (!e->crossK) {      // xattn engines: first use (beam search at width > 1, or more rows than the split-K decode path takes)
-        int r;
+        int r;                 // unless wx_reserve_cross_kv made room beforehand
         if ((r = dev_alloc(e, &e->crossK, cross_layer * e->cfg.n_text_layer * es, false))) return r;
-        if ((r = dev_alloc(e, &e->crossV, cross_layer * e->cfg.n_text_layer * es, false))) return r;
+        if ((r = dev_alloc(e, &e->crossV, cross_layer * e->cfg.n_text_layer * es, false))) { e->crossK = nullptr; return r; }
     }
     for (int i = 0; i < e->cfg.n_text_layer; ++i) {
         const LayerW& L = e->dec[i];
@@ -858,6 +858,18 @@ int wx_get_encoder_output(wx_engine* e, int32_t B, float* d_out, void* stream) {
     DeviceScope dev_scope(e);
     if (!d_out || B <= 0 || B > e->encoded_B) return fail(WX_ERR_INVALID, "no encoder output for that batch");
     WX_TRY(launch_to_f32(e->enc_out, e->dt, d_out, (int64_t)B * e->T * e->d, (hipStream_t)stream));
+    return WX_OK;
+}
+
+int wx_reserve_cross_kv(wx_engine* e) {
+    if (!e || !e->finalized) return fail(WX_ERR_STATE, "engine not finalized");
+    DeviceScope dev_scope(e);
+    if (e->crossK) return WX_OK;                              // fp32 / small bf16 engines own it since wx_finalize
+    const size_t bytes = (size_t)e->cfg.max_batch * e->Ht * e->T * HEAD_DIM * e->cfg.n_text_layer * dtype_size(e->dt);
+    int r;
+    if ((r = dev_alloc(e, &e->crossK, bytes, false))) { e->crossK = nullptr; return r; }
+    if ((r = dev_alloc(e, &e->crossV, bytes, false))) { e->crossK = nullptr; return r; }     // (the first half stays on the engine's free list)
+    e->cross_kv_B = 0;
     return WX_OK;
 }
 

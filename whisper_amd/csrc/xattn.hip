@@ -21,6 +21,7 @@
 // does not depend on the batch it is in.  Beam search at width > 1 keeps the K/V-cache kernel (attention.hip), which
 // shares one K/V stream among the beams of a window.
 #include "common.h"
+#include <cstdlib>
 
 namespace wx {
 
@@ -280,6 +281,286 @@ __global__ __launch_bounds__(512) void xattn_estream_kernel(XAttnArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// E-stream attention, round 3: NO LDS image.  The image (82 KB per 32-key tile at d = 1280) cost its store -- LDS stores move at
+// ~79 B/clk per CU, a third of the read rate: 0.43 us of a 1.7 us tile -- its transposed read-back and a barrier.  The tile a wave
+// needs TRANSPOSED for the context product is exactly the tile it holds in registers for the score product (wave w: k-steps
+// [w KSW, (w+1) KSW) of the width = the 16-wide column tiles [2 w KSW, 2 (w+1) KSW) of c), and the matrix pipe transposes for
+// free: with E as the A operand (row = key, k = feature) and a 0/1 selection matrix as B,
+//     D[key][n] = sum_f E[key][f] * [f == 16 c + n]  =  E[key][16 c + n]          (exact: one non-zero term)
+// comes back with the KEY index in the lane's registers (lane (g, r): keys 4g .. 4g+3, feature r) -- the A operand of the context
+// product after a bf16 pack.  60 MFMAs per wave and tile instead of 40 (the pipe was 12 % busy), no image store, no transposed
+// LDS reads, one barrier per tile, and the context product depends on nothing but the wave's own registers and P.
+//   HBM -> LDS by DMA (global_load_lds, no registers: a third register set does not fit next to the accumulators), each wave into
+//   its own 1-KiB-per-fragment slice of a staging tile; LDS -> registers by ds_read_b128 when the previous tile's registers die.
+//   tile t:   softmax(t) on wave qt < NQT (scores the phase before left) -> P, rescale factor         |  S product of tile t + 1
+//             barrier
+//             context product of tile t; its registers <- staging (tile t + 2); DMA of tile t + 3 into the staging slice
+// ---------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) void xa_gbl_void;
+typedef __attribute__((address_space(3))) void xa_lds_void;
+#define XA_WAIT_VM0() __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define XA_WAIT_LGKM0() __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define XA_BARRIER() __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")      /* LDS traffic only: the DMA stays in flight */
+
+template <int D, int NQT>
+__global__ __launch_bounds__(512) void xattn_estream_reg_kernel(XAttnArgs a) {
+    constexpr int KS_ALL = D / 32;
+    constexpr int NSW = (KS_ALL % 8 == 0) ? 8 : 4;             // waves that hold E (d = 384: 4 x 3 k-steps); the others only meet the barriers
+    constexpr int KSW = KS_ALL / NSW;                          // k-steps per wave = half its column tiles
+    constexpr int SB = NSW * NQT * 2 * 64;
+    __shared__ __attribute__((aligned(16))) char lds[2 * KS_ALL * 1024 + 2 * SB * 16 + 2 * NQT * 64 * 16 + 2 * NQT * 16 * 4 + NQT * 16 * 4];
+    char* const stage = lds;                                                       // [S wave][key half][k-step][64 lanes][16 B]
+    f32x4* const sbuf = reinterpret_cast<f32x4*>(lds + 2 * KS_ALL * 1024);         // 2 x [S wave][query tile][key half][lane]
+    bf16x8* const pbuf = reinterpret_cast<bf16x8*>(lds + 2 * KS_ALL * 1024 + 2 * SB * 16);      // 2 x [query tile][lane]
+    float* const abuf = reinterpret_cast<float*>(lds + 2 * KS_ALL * 1024 + 2 * SB * 16 + 2 * NQT * 64 * 16);   // 2 x [query tile][16]
+    float* const lbuf = abuf + 2 * NQT * 16;
+    const int row = blockIdx.x / a.n_split, split = blockIdx.x % a.n_split;
+    const int win = row / a.group;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    const bool s_role = NSW == 8 || wid < NSW;                 // wave-uniform
+    const int kw = s_role ? wid : 0;
+    const int T = a.T, H = a.H;
+
+    bf16x8 qf[NQT][KSW];
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {
+        const int q = qt * 16 + r;
+        const bf16* qp = a.qt + ((int64_t)row * H + (q < H ? q : H - 1)) * D + kw * KSW * 32 + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KSW; ++ks) {
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(qp + ks * 32);
+            if (q >= H) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            qf[qt][ks] = v;
+        }
+    }
+    // selection operands: as B (column n = r, k = 8g + j): 1 where 8g + j == 16 c + r
+    bf16x8 sel[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sel[c][j] = (8 * g + j == 16 * c + r) ? (bf16)1.0f : (bf16)0.0f;
+    XA_WAIT_VM0();                                             // the ordinary loads above are done before the first DMA is issued
+
+    const int nt = a.nt16 / 2;
+    const int t0 = (int)((int64_t)split * nt / a.n_split), t1 = (int)((int64_t)(split + 1) * nt / a.n_split);
+    const char* const ebase = reinterpret_cast<const char*>(a.E) + ((int64_t)win * a.nt16 * KS_ALL + kw * KSW) * 1024 + lane * 16;
+    char* const myst = stage + kw * 2 * KSW * 1024;            // this wave's slice of the staging tile
+    auto dma_tile = [&](int t) {                               // wave-uniform condition; 2 KSW loads of 1 KiB, no registers
+        if (s_role && t < t1) {
+            const char* src = ebase + (int64_t)t * (2 * KS_ALL * 1024);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int ks = 0; ks < KSW; ++ks)
+                    __builtin_amdgcn_global_load_lds((xa_gbl_void*)(src + (hh * KS_ALL + ks) * 1024), (xa_lds_void*)(myst + (hh * KSW + ks) * 1024), 16, 0, 2);
+        }
+    };
+    auto fill_set = [&](bf16x8 (&st)[2][KSW]) {               // staging slice -> registers (past the split's end: stale data nobody uses)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int ks = 0; ks < KSW; ++ks) st[hh][ks] = *reinterpret_cast<const bf16x8*>(myst + (hh * KSW + ks) * 1024 + lane * 16);
+    };
+    // context accumulators: query tile 0 (heads 0..15) one per column tile; the heads past 16 (at most 4: d = 1280 has 20) PACKED,
+    // four column tiles per accumulator -- column tile it = 4u + s lives in columns 4s..4s+3 of accX[u], put there by a P operand
+    // that is zero outside those columns (a full second query tile would be 40 registers of which 30 hold padding)
+    constexpr int NX = NQT == 2 ? (2 * KSW + 3) / 4 : 0;
+    f32x4 accC[2 * KSW], accX[NX > 0 ? NX : 1];
+#pragma unroll
+    for (int it = 0; it < 2 * KSW; ++it) accC[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NX; ++u) accX[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;                      // softmax waves only: query tile wid
+
+    auto s_phase = [&](bf16x8 (&st)[2][KSW], int sb) {
+        if (s_role && !(XA_SKIP & 1)) {
+            f32x4 acc[NQT][2];
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) acc[qt][hh] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KSW; ++ks)
+#pragma unroll
+                for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) acc[qt][hh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st[hh][ks], qf[qt][ks], acc[qt][hh], 0, 0, 0);
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) sbuf[sb * SB + ((wid * NQT + qt) * 2 + hh) * 64 + lane] = acc[qt][hh];
+        }
+    };
+    auto softmax = [&](int t, int sb) {
+        if (wid < NQT && !(XA_SKIP & 8)) {              // lane (g, r) holds keys 4g..4g+3 of both 16-key halves for query r
+            f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+#pragma unroll
+            for (int w = 0; w < NSW; ++w) {                     // fixed order: the K slices in ascending order
+                s0 += sbuf[sb * SB + ((w * NQT + wid) * 2 + 0) * 64 + lane];
+                s1 += sbuf[sb * SB + ((w * NQT + wid) * 2 + 1) * 64 + lane];
+            }
+            if ((t + 1) * XA_KT > T) {                          // only the last tile of the window can run past the keys
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (t * XA_KT + 4 * g + j >= T) s0[j] = -INFINITY;
+                    if (t * XA_KT + 16 + 4 * g + j >= T) s1[j] = -INFINITY;
+                }
+            }
+            float mt = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+            mt = fmaxf(mt, __shfl_xor(mt, 16));
+            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            const float mn = fmaxf(m_run, mt);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - mn) * XA_LOG2E);
+            const float mn2 = mn * XA_LOG2E;
+            float p[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                p[j] = __builtin_amdgcn_exp2f(fmaf(s0[j], XA_LOG2E, -mn2));
+                p[4 + j] = __builtin_amdgcn_exp2f(fmaf(s1[j], XA_LOG2E, -mn2));
+            }
+            l_run = l_run * alpha + (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])));
+            m_run = mn;
+            bf16x8 pv;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pv[j] = (bf16)p[j];
+            pbuf[(sb * NQT + wid) * 64 + lane] = pv;
+            if (g == 0) abuf[(sb * NQT + wid) * 16 + r] = alpha;
+        }
+    };
+    // context product of one tile from the registers it was read into
+    auto c_phase = [&](bf16x8 (&st)[2][KSW], int sb) {
+        if (s_role && !(XA_SKIP & 4)) {
+            const bf16x8 pf = pbuf[(sb * NQT + 0) * 64 + lane];
+            {
+                const float alpha = abuf[(sb * NQT + 0) * 16 + r];
+                if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
+#pragma unroll
+                    for (int it = 0; it < 2 * KSW; ++it) accC[it] *= alpha;
+                }
+            }
+            bf16x8 px = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};        // P of head 16 + (r & 3) for this lane's keys
+            if (NQT == 2) {
+                px = pbuf[(sb * NQT + 1) * 64 + g * 16 + (r & 3)];
+                const float alpha = abuf[(sb * NQT + 1) * 16 + (r & 3)];
+                if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
+#pragma unroll
+                    for (int u = 0; u < NX; ++u) accX[u] *= alpha;
+                }
+            }
+            const bf16x8 none = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+            // the transposing MFMAs run one column tile ahead of the context MFMAs that consume them
+            f32x4 d0[2], d1[2];
+            d0[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st[0][0], sel[0], zero, 0, 0, 0);       // E[keys 4g..4g+3][16 c + r], half 0
+            d1[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st[1][0], sel[0], zero, 0, 0, 0);       // ... half 1
+#pragma unroll
+            for (int it = 0; it < 2 * KSW; ++it) {
+                if (it + 1 < 2 * KSW) {
+                    d0[(it + 1) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st[0][(it + 1) >> 1], sel[(it + 1) & 1], zero, 0, 0, 0);
+                    d1[(it + 1) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st[1][(it + 1) >> 1], sel[(it + 1) & 1], zero, 0, 0, 0);
+                }
+                bf16x8 ef;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { ef[j] = (bf16)d0[it & 1][j]; ef[4 + j] = (bf16)d1[it & 1][j]; }
+                accC[it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef, pf, accC[it], 0, 0, 0);
+                if (NQT == 2) {
+                    const bf16x8 pxs = (r >> 2) == (it & 3) ? px : none;
+                    accX[it >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef, pxs, accX[it >> 2], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    // One barrier interval: the softmax of tile t + 1 FIRST, on its NQT waves (LDS + VALU work that runs under the matrix work of
+    // the waves they share a SIMD with), the context product of tile t from register set X, X <- staging (tile t + 2), the DMA
+    // of tile t + 3, and the S product of tile t + 2 from the registers just filled.  Scores run two tiles ahead of the context
+    // product, score tiles and P are double-buffered, so one barrier per tile separates every producer from its consumer.
+    auto tile = [&](bf16x8 (&X)[2][KSW], int t) {
+        const int sb = (t - t0) & 1;
+        if (t + 1 < t1) softmax(t + 1, sb ^ 1);       // (wave-uniform; the running maximum and sum must not see tiles of another split)
+        c_phase(X, sb);
+        XA_WAIT_VM0();                // tile t + 2 has landed in this wave's staging slice
+        if (!(XA_SKIP & 16)) fill_set(X);
+        XA_WAIT_LGKM0();              // ... and is in registers: the slice may be overwritten
+        if (!(XA_SKIP & 2)) dma_tile(t + 3);
+        s_phase(X, sb);               // scores of tile t + 2 into the buffer softmax(t) read in the previous interval
+        XA_BARRIER();
+    };
+    bf16x8 stA[2][KSW], stB[2][KSW];
+    dma_tile(t0);
+    XA_WAIT_VM0();
+    fill_set(stA);
+    XA_WAIT_LGKM0();
+    dma_tile(t0 + 1);
+    s_phase(stA, 0);
+    XA_WAIT_VM0();
+    fill_set(stB);
+    XA_WAIT_LGKM0();
+    dma_tile(t0 + 2);
+    s_phase(stB, 1);
+    XA_BARRIER();
+    softmax(t0, 0);
+    XA_BARRIER();
+    int t = t0;
+    for (; t + 1 < t1; t += 2) {
+        tile(stA, t);
+        tile(stB, t + 1);
+    }
+    if (t < t1) tile(stA, t);
+    XA_WAIT_VM0();
+    // ---- partial context, normalised by this split's own sum; lane holds c[q = r][i = 16 itile + 4g .. +3] -----------------
+    if (wid < NQT) {
+        float l = l_run;
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const int q = wid * 16 + r;
+        if (g == 0) {
+            lbuf[wid * 16 + r] = l;
+            if (q < H) {
+                float* mp = a.ml + (((int64_t)row * a.n_split + split) * H + q) * 2;
+                mp[0] = m_run; mp[1] = l;
+            }
+        }
+    }
+    __syncthreads();
+    if (s_role) {
+        {
+            const float l = lbuf[r];
+            const float inv = l > 0.f ? 1.0f / l : 0.f;
+            if (r < H) {
+                bf16* cp = a.cpart + (((int64_t)row * a.n_split + split) * H + r) * D + kw * KSW * 32 + 4 * g;
+#pragma unroll
+                for (int it = 0; it < 2 * KSW; ++it) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (bf16)(accC[it][j] * inv);
+                    *reinterpret_cast<bf16x4*>(cp + it * 16) = o;
+                }
+            }
+        }
+        if (NQT == 2) {              // packed heads: lane (g, r) holds head 16 + (r & 3), column tile 4u + (r >> 2), features 4g .. 4g+3
+            const int q = 16 + (r & 3);
+            const float l = lbuf[q];
+            const float inv = l > 0.f ? 1.0f / l : 0.f;
+            if (q < H) {
+                bf16* cp = a.cpart + (((int64_t)row * a.n_split + split) * H + q) * D + kw * KSW * 32 + 4 * g;
+#pragma unroll
+                for (int u = 0; u < NX; ++u) {
+                    const int it = 4 * u + (r >> 2);
+                    if (it < 2 * KSW) {
+                        bf16x4 o;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = (bf16)(accX[u][j] * inv);
+                        *reinterpret_cast<bf16x4*>(cp + it * 16) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // encoder output [windows][T][D] row-major -> MFMA-fragment order [windows][nt16][D/32][64 lanes][8], zero beyond key T - 1
 __global__ __launch_bounds__(256) void xattn_pack_e_kernel(const bf16* __restrict__ E, bf16* __restrict__ Ef, int T, int D, int nt16, int64_t pieces) {
     const int ks_all = D / 32;
@@ -484,14 +765,28 @@ int launch_xattn_estream(const XAttnArgs& a, hipStream_t st) {
     if (a.rows <= 0 || a.group < 1 || a.n_split < 1 || a.n_split > 8 || a.T <= 0 || !a.qt || !a.E || !a.cpart || !a.ml || a.H * 64 != a.d) return -1;
     if (a.nt16 * 16 < a.T || (a.nt16 & 1) || a.nt16 / 2 < a.n_split) return -1;
     const dim3 grid(a.rows * a.n_split), block(512);
+    const bool image = getenv("WX_XATTN_IMAGE") != nullptr;       // A/B: round 2's kernel (E tile through an LDS image); read per launch -- a captured graph keeps what it captured
+    if (image) {
+        switch (a.d) {
+            case 384: hipLaunchKernelGGL((xattn_estream_kernel<384, 1>), grid, block, 0, st, a); break;
+            case 512: hipLaunchKernelGGL((xattn_estream_kernel<512, 1>), grid, block, 0, st, a); break;
+            case 768: hipLaunchKernelGGL((xattn_estream_kernel<768, 1>), grid, block, 0, st, a); break;
+            case 1024: hipLaunchKernelGGL((xattn_estream_kernel<1024, 1>), grid, block, 0, st, a); break;
+            case 1280: hipLaunchKernelGGL((xattn_estream_kernel<1280, 2>), grid, block, 0, st, a); break;
+            case 128: hipLaunchKernelGGL((xattn_estream_kernel<128, 1>), grid, block, 0, st, a); break;
+            case 256: hipLaunchKernelGGL((xattn_estream_kernel<256, 1>), grid, block, 0, st, a); break;
+            default: return -1;
+        }
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     switch (a.d) {
-        case 384: hipLaunchKernelGGL((xattn_estream_kernel<384, 1>), grid, block, 0, st, a); break;
-        case 512: hipLaunchKernelGGL((xattn_estream_kernel<512, 1>), grid, block, 0, st, a); break;
-        case 768: hipLaunchKernelGGL((xattn_estream_kernel<768, 1>), grid, block, 0, st, a); break;
-        case 1024: hipLaunchKernelGGL((xattn_estream_kernel<1024, 1>), grid, block, 0, st, a); break;
-        case 1280: hipLaunchKernelGGL((xattn_estream_kernel<1280, 2>), grid, block, 0, st, a); break;
-        case 128: hipLaunchKernelGGL((xattn_estream_kernel<128, 1>), grid, block, 0, st, a); break;
-        case 256: hipLaunchKernelGGL((xattn_estream_kernel<256, 1>), grid, block, 0, st, a); break;
+        case 384: hipLaunchKernelGGL((xattn_estream_reg_kernel<384, 1>), grid, block, 0, st, a); break;
+        case 512: hipLaunchKernelGGL((xattn_estream_reg_kernel<512, 1>), grid, block, 0, st, a); break;
+        case 768: hipLaunchKernelGGL((xattn_estream_reg_kernel<768, 1>), grid, block, 0, st, a); break;
+        case 1024: hipLaunchKernelGGL((xattn_estream_reg_kernel<1024, 1>), grid, block, 0, st, a); break;
+        case 1280: hipLaunchKernelGGL((xattn_estream_reg_kernel<1280, 2>), grid, block, 0, st, a); break;
+        case 128: hipLaunchKernelGGL((xattn_estream_reg_kernel<128, 1>), grid, block, 0, st, a); break;
+        case 256: hipLaunchKernelGGL((xattn_estream_reg_kernel<256, 1>), grid, block, 0, st, a); break;
         default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;

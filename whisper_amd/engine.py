@@ -229,6 +229,11 @@ class WhisperEngine:
         _lib.check(self.lib.wx_get_encoder_output(self.handle, B, _ptr(out), self._stream()), "wx_get_encoder_output")
         return out
 
+    def reserve_cross_kv(self) -> None:
+        """Allocate the per-layer cross K/V cache now instead of inside the first beam-search call (bf16 engines with
+        max_batch >= 32 do not own one otherwise; 15.7 GB at large-v3 x 64 rows): ``wx_reserve_cross_kv``."""
+        _lib.check(self.lib.wx_reserve_cross_kv(self.handle), "wx_reserve_cross_kv")
+
     def compact_windows(self, keep: Sequence[int]) -> None:
         """Keep the windows ``keep`` (strictly ascending slots of the last encode) as slots 0..len(keep)-1, so that the next
         decode call runs on them alone: upstream's temperature fallback re-decodes only the windows that failed its checks."""

@@ -83,8 +83,13 @@ try:
         model=WHISPER_MODEL, checkpoint=_AMD.get("checkpoint"), vocab=_AMD.get("vocab"),
         precision=_AMD.get("precision", "bf16"), max_batch=int(_AMD.get("max_batch", 16)),
         allow_synthetic_weights=bool(_AMD.get("allow_synthetic_weights", False)),
-        confidence_mode=_AMD.get("confidence_mode", "reference"), lanes=int(_AMD.get("lanes", 1)))
+        confidence_mode=_AMD.get("confidence_mode", "reference"), lanes=int(_AMD.get("lanes", 1)),
+        expect_beam_search=bool(_AMD.get("beam_size")) and str(_AMD.get("decode_mode", "sequential")) == "windows")
     logger.info(f"Whisper model '{WHISPER_MODEL}' loaded on {device}")
+    if str(_AMD.get("decode_mode", "sequential")) == "sequential" and (_AMD.get("beam_size") or int(_AMD.get("lanes", 1)) > 1):
+        # the default mode changed from "windows" to "sequential" in round 2: say what that does to an older configuration
+        logger.warning("whisper_amd: decode_mode is 'sequential' (the default: upstream's own loop, greedy with temperature fallback); "
+                       "whisper_amd.beam_size and whisper_amd.lanes only apply to decode_mode 'windows' and are ignored")
 except Exception as e:   # noqa: BLE001 — same as the reference: never fail the import
     logger.error(f"Failed to load Whisper model: {str(e)}")
     device = "cpu"

@@ -33,13 +33,17 @@ _STATE: Dict[str, object] = {"engine": None, "tokenizer": None, "settings": None
 
 def configure(model: str = "base", checkpoint: Optional[str] = None, vocab: Optional[str] = None,
               precision: str = "bf16", max_batch: int = 16, device: Optional[int] = None,
-              allow_synthetic_weights: bool = False, confidence_mode: str = "reference", seed: int = 0, lanes: int = 1):
+              allow_synthetic_weights: bool = False, confidence_mode: str = "reference", seed: int = 0, lanes: int = 1,
+              expect_beam_search: bool = False):
     """Create the process-global engine (the counterpart of the reference's module-level ``whisper.load_model``,
     ref:speech_recognition.py:20-26).  ``checkpoint`` is a LOCAL openai ``.pt`` or HF ``.safetensors`` file; without
     one, ``allow_synthetic_weights`` must be set explicitly (seeded random weights, for benchmarks and tests).
     ``lanes`` > 1 keeps that many batches of a long file in flight on the GPU (engine replicas on their own host threads and
-    streams, whisper_amd/lanes.py: +24 % throughput at 2, +35 % at 4 for large-v3 at 64 windows per batch; one more copy of
-    weights and workspace each); windows mode only, the sequential loop uses the first replica."""
+    streams, whisper_amd/lanes.py: +24 % throughput at 2, +35 % at 4 for large-v3 at 64 windows per batch; one more
+    workspace each, the weights are shared); windows mode only, the sequential loop uses the first replica.  bf16 results depend
+    on ``lanes`` by rounding noise (it sets the key split of the cross-attention stream), fp32 results do not.
+    ``expect_beam_search``: allocate every engine's cross K/V cache now (bf16, max_batch >= 32: 15.7 GB per engine at large-v3 x
+    64 rows) instead of inside the first ``beam_size`` call, so that running out of memory shows here."""
     from .engine import WhisperEngine
     if checkpoint:
         dims, sd = ck.load_checkpoint(checkpoint)
@@ -66,6 +70,9 @@ def configure(model: str = "base", checkpoint: Optional[str] = None, vocab: Opti
         eng = EngineLanes.create(make, int(lanes))
     else:
         eng = make()
+    if expect_beam_search:
+        for e_i in (eng.engines if int(lanes) > 1 else [eng]):
+            e_i.reserve_cross_kv()
     _STATE["engine"] = eng
     _STATE["tokenizer"] = tokenizer
     _STATE["settings"] = {"model": model, "confidence_mode": confidence_mode}
