@@ -399,7 +399,7 @@ def main():
         # corrections), committed under profiles/ -- a replayed constant, not something this run measured; other shapes
         # than the default workload's report none
         traffic, traffic_source = None, None
-        for name in (("r02_estream_pmc.json",) if estream else ("r01_cross_attn_pmc.json",)):
+        for name in (("r03_estream_pmc.json", "r02_estream_pmc.json") if estream else ("r01_cross_attn_pmc.json",)):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc) and (args.model, B, args.precision) == ("large-v3", 64, "bf16"):
                 try:

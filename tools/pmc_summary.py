@@ -15,7 +15,7 @@ out = {}
 for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
     b = sum(v) / len(v) * 1024 * 2
     print(f"{k[:80]:80s} launches={len(v):5d} hbm_bytes_per_launch={b:16.0f}")
-    if (sys.argv[3] if len(sys.argv) > 3 else "xattn_estream_kernel") in k:
+    if (sys.argv[3] if len(sys.argv) > 3 else "xattn_estream") in k:
         out = {"kernel": k, "launches": len(v), "hbm_bytes_per_launch": b, "counter": "FETCH_SIZE (KiB) x 1024 x 2",
                "source": "rocprofv3 --pmc FETCH_SIZE, own pass, bench.py --steps 1 --warmup 0 --max-new-tokens 4"}
 if len(sys.argv) > 2 and out:
