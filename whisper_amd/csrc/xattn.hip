@@ -30,7 +30,7 @@ typedef __attribute__((ext_vector_type(8))) short i16x8;
 constexpr float XA_LOG2E = 1.4426950408889634f;
 #ifndef XA_SKIP
 #define XA_SKIP 0                                   // diagnostics (tools/mb_xattn.sh), bit mask of the parts left out of the E-stream kernel: 1 = S product,
-#endif                                              // 2 = global loads inside the loop, 4 = C phase, 8 = softmax, 16 = image write
+#endif                                              // 2 = global loads inside the loop, 4 = C phase, 8 = softmax, 16 = image write / staging -> register fill, 32 = the wait for the staged tile
 #ifndef XA_CPD
 #define XA_CPD 2
 #endif
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(512) void xattn_estream_reg_kernel(XAttnArgs a) {
         const int sb = (t - t0) & 1;
         if (t + 1 < t1) softmax(t + 1, sb ^ 1);       // (wave-uniform; the running maximum and sum must not see tiles of another split)
         c_phase(X, sb);
-        XA_WAIT_VM0();                // tile t + 2 has landed in this wave's staging slice
+        if (!(XA_SKIP & 32)) XA_WAIT_VM0();                // tile t + 2 has landed in this wave's staging slice
         if (!(XA_SKIP & 16)) fill_set(X);
         XA_WAIT_LGKM0();              // ... and is in registers: the slice may be overwritten
         if (!(XA_SKIP & 2)) dma_tile(t + 3);
