@@ -3,11 +3,12 @@
 out=${1:-gpurun_out/other_configs.txt}
 : > "$out"
 run() {
-    timeout -k 10 300 python bench.py "$@" --no-cpu-baseline --no-profile-pass > gpurun_out/oc.log 2>&1 || { echo "$*: FAILED" >> "$out"; tail -3 gpurun_out/oc.log >> "$out"; return 1; }
+    timeout -k 10 300 python bench.py "$@" --no-cpu-baseline --no-profile-pass --no-single-batch > gpurun_out/oc.log 2>&1 || { echo "$*: FAILED" >> "$out"; tail -3 gpurun_out/oc.log >> "$out"; return 1; }
+    echo "done: $*"
     python - "$*" >> "$out" <<'PY'
 import json, sys
 l = json.loads([x for x in open("gpurun_out/oc.log") if x.startswith('{"metric"')][-1])
-print(f"{sys.argv[1]}: {l['value']:.1f} RTFx, {l['ms_per_step']:.1f} ms per step,", {k: round(v['ms'], 1) for k, v in l['stages'].items()})
+print(f"{sys.argv[1]}: {l['value']:.1f} RTFx, {l['ms_per_step']:.1f} ms per step,", {k: round(v['ms'], 1) for k, v in l['stages'].items() if isinstance(v, dict)})
 PY
 }
 run --model turbo --batch 64 && run --model turbo --batch 80 && run --batch 80 && run --batch 1 && run --batch 4 && run --batch 16 && run --batch 32 && \
