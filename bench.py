@@ -57,6 +57,8 @@ def parse():
                    "instead of sharing lane 0's (wx_create_shared)")
     p.add_argument("--no-single-batch", action="store_true", help="skip the single_batch leg (a few steps of ONE batch at a time on an engine "
                    "sized for the whole GPU, after the timed region)")
+    p.add_argument("--overlap-encoders", action="store_true", help="A/B: lanes may run their encoders side by side (round 2's behaviour); default: "
+                   "one encoder at a time per GPU (EngineLanes' encode gate)")
     p.add_argument("--dry-run", action="store_true", help="launcher rehearsal: every rank reports its rank environment and exits before touching the GPU")
     return p.parse_args()
 
@@ -246,7 +248,7 @@ def main():
     if args.lanes < 1:
         raise SystemExit("--lanes must be >= 1")
     lanes = EngineLanes.create(lambda n: WhisperEngine(dims, sd, precision=args.precision, max_batch=B * max(1, args.beam), device=local_rank, n_lanes=n),
-                               args.lanes, share_weights=not args.separate_weights)
+                               args.lanes, share_weights=not args.separate_weights, one_encoder_at_a_time=not args.overlap_encoders)
     eng = lanes.engines[0]
     prompt = eng.initial_tokens(0)
 
@@ -467,6 +469,7 @@ def main():
             single["kernel_frac"] = single["kernel_achieved_GBs"] / HBM_PEAK_GBS
             out["single_batch"] = single
         out["config"]["weights_shared_by_lanes"] = not args.separate_weights
+        out["config"]["one_encoder_at_a_time"] = not args.overlap_encoders and args.lanes > 1
         out["config"]["weight_bytes_per_gpu"] = sum(e_i.weight_bytes for e_i in lanes.engines)
         out["config"]["workspace_bytes_per_gpu"] = sum(e_i.workspace_bytes for e_i in lanes.engines)
         if not args.no_cpu_baseline and world == 1:

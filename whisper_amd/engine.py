@@ -60,6 +60,7 @@ class WhisperEngine:
             tok_sot_lm=t.sot_lm, tok_no_speech=t.no_speech, tok_no_timestamps=t.no_timestamps,
             tok_timestamp_begin=t.timestamp_begin, tok_blank=t.blank, n_lanes=int(n_lanes))
         self.n_lanes = int(n_lanes)
+        self.encode_gate = None           # a lock shared by the lanes of a GPU (EngineLanes sets it); None: encode() never waits
         handle = ctypes.c_void_p()
         if share_weights_with is not None:
             p = share_weights_with
@@ -213,8 +214,16 @@ class WhisperEngine:
     # -- encoder ------------------------------------------------------------------------------------------
     def encode(self, mel: torch.Tensor, win_stride: int, row_stride: int, n_valid_frames: int, B: int) -> None:
         assert mel.dtype == torch.float32 and mel.is_cuda
-        _lib.check(self.lib.wx_encode(self.handle, _ptr(mel), win_stride, row_stride, n_valid_frames, B, self._stream()),
-                   "wx_encode")
+        gate = self.encode_gate
+        if gate is None:
+            _lib.check(self.lib.wx_encode(self.handle, _ptr(mel), win_stride, row_stride, n_valid_frames, B, self._stream()),
+                       "wx_encode")
+            return
+        # one encoder at a time among the lanes of a GPU (whisper_amd/lanes.py): held until its kernels have finished
+        with gate:
+            _lib.check(self.lib.wx_encode(self.handle, _ptr(mel), win_stride, row_stride, n_valid_frames, B, self._stream()),
+                       "wx_encode")
+            torch.cuda.current_stream(self.torch_device).synchronize()
 
     def encode_windows(self, mel_windows: torch.Tensor) -> None:
         """``mel_windows [B, n_mels, 3000]`` fp32 on device."""

@@ -81,18 +81,28 @@ class EngineLanes:
     engine, so an ``EngineLanes`` can stand wherever a ``WhisperEngine`` is used (whisper_amd.dist.transcribe_sharded); only
     ``transcribe_mel`` is different: it deals the batches of a file out over the lanes."""
 
-    def __init__(self, engines: Sequence):
+    def __init__(self, engines: Sequence, one_encoder_at_a_time: bool = True):
         if not engines:
             raise ValueError("at least one engine")
         e0 = engines[0]
         for e in engines[1:]:
             if (e.dims, e.precision, e.max_batch, e.torch_device) != (e0.dims, e0.precision, e0.max_batch, e0.torch_device):
                 raise ValueError("lanes must be replicas of one engine configuration on one device")
+        # One encoder at a time: the encoder is the one stage that fills the chip by itself (MFMA-bound 256x256 tiles on every CU),
+        # so two of them side by side only take turns and evict each other's panels from L2, while the decode loops of the other
+        # lanes -- which do fill the holes of an encoder -- wait behind both.  A host lock around encode(), held until its kernels
+        # have finished, keeps the lanes' encoders apart: 672.6 instead of 681.0 ms per step at 4 lanes x 64 windows of large-v3
+        # (profiles/r03_cu_share_and_hw_queues.txt, section 4).  Results do not change (same kernels, same order per lane).
+        if one_encoder_at_a_time and len(engines) > 1 and hasattr(e0, "encode_gate"):
+            gate = threading.Lock()
+            for e in engines:
+                e.encode_gate = gate
         self._lanes = [_Lane(e, i) for i, e in enumerate(engines)]
         self._next = 0
 
     @classmethod
-    def create(cls, make_engine: Callable[[int], object], n_lanes: int, share_weights: bool = True) -> "EngineLanes":
+    def create(cls, make_engine: Callable[[int], object], n_lanes: int, share_weights: bool = True,
+               one_encoder_at_a_time: bool = True) -> "EngineLanes":
         """``make_engine(n_lanes)`` builds the first engine; it should pass ``n_lanes`` on to ``WhisperEngine`` so that the
         engine sizes its cross-attention grid for its share of the GPU.  The other lanes are ``replica()``s of it -- same
         configuration, the same device weights (``wx_create_shared``) -- unless ``share_weights`` is False or the engine has
@@ -108,7 +118,7 @@ class EngineLanes:
             for e in engines:
                 e.close()
             raise
-        return cls(engines)
+        return cls(engines, one_encoder_at_a_time=one_encoder_at_a_time)
 
     @property
     def n_lanes(self) -> int:
