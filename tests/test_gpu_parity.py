@@ -238,6 +238,47 @@ def test_stream_kernels_with_and_without_the_lds_image_are_bit_identical(monkeyp
         eng.close()
 
 
+@pytest.mark.parametrize("name", ["micro", "micro256", "tiny", "base1", "small1", "medium1", "large1"])
+def test_key_split_combine_inside_the_output_projection_is_bit_identical_bf16(monkeypatch, name):
+    """Up to four decode rows on the K/V form of the cross-attention: the key splits' states are combined in the prologue of the
+    output projection (gemm.hip launch_gemm_acomb: one launch less per layer) instead of attn_decode_combine_kernel.  Same function,
+    same rounding point, same MFMA order: logits, ids and log-probabilities are BIT-identical to the stand-alone combine
+    (WX_NO_FUSE_COMBINE=1) at every width class and split count, eager and captured, and rows 0..3 of a 5-row batch (stand-alone
+    combine by size) equal the same rows decoded as 4."""
+    import dataclasses
+    from whisper_amd.engine import WhisperEngine
+    if name.endswith("1"):
+        full = {"base1": "base", "small1": "small", "medium1": "medium", "large1": "large-v3"}[name]
+        dims = dataclasses.replace(ck.dims_for(full), n_audio_layer=1, n_text_layer=3)
+    else:
+        dims = ck.dims_for(name)
+    sd = ck.synthetic_state_dict(dims, seed=0, eot_boost=3.0)
+    eng = WhisperEngine(dims, sd, precision="bf16", max_batch=5)
+    try:
+        assert eng.cross_form == "kv" and eng.cross_key_splits > 1
+        mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(s), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000] for s in range(5)])
+        tok = eng.tok
+        toks = torch.tensor([[tok.sot, tok.lang(0), tok.transcribe, tok.no_timestamps, 100, 2000, 31337, 7, 50000]] * 5)
+        init = wo.initial_tokens(tok, 0)
+        eng.encode_windows(mels)
+        five = eng.decoder_logits(toks).cpu()                        # 5 rows: the stand-alone combine launch
+        for rows in (1, 2, 4):
+            eng.encode_windows(mels[:rows])
+            fused = eng.decoder_logits(toks[:rows]).cpu()
+            a = eng.decode_greedy(rows, init, max_new_tokens=12, use_graph=False)
+            g = eng.decode_greedy(rows, init, max_new_tokens=12, use_graph=True)
+            monkeypatch.setenv("WX_NO_FUSE_COMBINE", "1")
+            plain = eng.decoder_logits(toks[:rows]).cpu()
+            b = eng.decode_greedy(rows, init, max_new_tokens=12, use_graph=False)
+            monkeypatch.delenv("WX_NO_FUSE_COMBINE")
+            assert torch.isfinite(fused).all() and torch.equal(fused, plain) and torch.equal(fused, five[:rows])
+            for x in (b, g):
+                assert torch.equal(a["tokens"], x["tokens"]) and torch.equal(a["sum_logprobs"], x["sum_logprobs"])
+                assert torch.equal(a["no_speech_probs"], x["no_speech_probs"])
+    finally:
+        eng.close()
+
+
 def test_encoder_parity_256_tiles_bf16(models):
     """3 windows of a 256-wide model: M = 4500 rows (a ragged last tile) takes the 256x256 LDS-DMA GEMM kernel; the decoder
     runs its split-K GEMMs at K = 256 / 1024."""

@@ -364,17 +364,8 @@ template <typename T>
 __global__ __launch_bounds__(64) void attn_decode_combine_kernel(AttnArgs a) {
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H, d = threadIdx.x;
     const float* pp = a.partial + (int64_t)blockIdx.x * a.n_split * (HEAD_DIM + 2);
-    float M = -INFINITY;
-    for (int s = 0; s < a.n_split; ++s) M = fmaxf(M, pp[s * (HEAD_DIM + 2) + HEAD_DIM]);
-    float L = 0.f, acc = 0.f;
-    for (int s = 0; s < a.n_split; ++s) {
-        const float ms = pp[s * (HEAD_DIM + 2) + HEAD_DIM];
-        const float f = (ms == -INFINITY) ? 0.f : exp2f((ms - M) * LOG2E);
-        L += pp[s * (HEAD_DIM + 2) + HEAD_DIM + 1] * f;
-        acc += pp[s * (HEAD_DIM + 2) + d] * f;
-    }
     T* op = reinterpret_cast<T*>(a.O) + (int64_t)b * a.o_sb + h * a.o_sh + d;
-    *op = (T)(acc / L);
+    *op = (T)attn_combine_splits(pp, a.n_split, d);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -549,9 +540,17 @@ int launch_attn_decode(const AttnArgs& a, hipStream_t st) {
         case 5: hipLaunchKernelGGL((attn_decode_kernel<T, 5>), grid, block, 0, st, a); break;                   \
         default: hipLaunchKernelGGL((attn_decode_kernel<T, 8>), grid, block, 0, st, a); break;                  \
     }                                                                                                           \
-    if (a.n_split > 1) hipLaunchKernelGGL(attn_decode_combine_kernel<T>, dim3(a.B * a.H), dim3(64), 0, st, a);
+    if (a.n_split > 1 && !a.defer_combine) hipLaunchKernelGGL(attn_decode_combine_kernel<T>, dim3(a.B * a.H), dim3(64), 0, st, a);
+    if (a.n_split > ACOMB_MAX_SPLIT) return -1;
     if (a.dt == DT_BF16) { WX_LAUNCH_CROSS(bf16) } else { WX_LAUNCH_CROSS(float) }
 #undef WX_LAUNCH_CROSS
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_attn_combine(const AttnArgs& a, hipStream_t st) {
+    if (check_common(a) || a.n_split < 2 || a.n_split > ACOMB_MAX_SPLIT || !a.partial || !a.O) return -1;
+    if (a.dt == DT_BF16) hipLaunchKernelGGL(attn_decode_combine_kernel<bf16>, dim3(a.B * a.H), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(attn_decode_combine_kernel<float>, dim3(a.B * a.H), dim3(64), 0, st, a);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

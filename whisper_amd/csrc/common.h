@@ -83,17 +83,53 @@ struct GemmArgs {
     int n_split = 1;
     float* partial = nullptr;
     GemmEpilogue ep;
+    // launch_gemm_acomb only (M <= ACOMB_ROWS): the activation is not read from A; row m, column k of it is the cross-attention
+    // output of head k / 64, element k % 64, combined from the key splits' partial states ac_partial[(m*ac_H + h)*ac_nsplit + s][66]
+    // exactly as attn_decode_combine_kernel combines them (attn_combine_splits below)
+    const float* ac_partial = nullptr; int ac_nsplit = 0, ac_H = 0;
 };
+constexpr int ACOMB_ROWS = 4, ACOMB_MAX_SPLIT = 6;
 // Returns 0 or a negative wx_status. Chooses the kernel from (dtype, M).
 int launch_gemm(const GemmArgs& g, hipStream_t st);
 // bf16 decode GEMM (M <= DG_MAX_ROWS) with K halved inside the workgroup and the full epilogue applied (no partial tiles);
 // needs g.Wpk.  0 = launched, 1 = shape not covered (use the split-K path), < 0 = error.
 int launch_gemm_khalf(const GemmArgs& g, hipStream_t st);
+// The split-K decode GEMM behind the K/V-form cross-attention at <= ACOMB_ROWS rows, with the combine of the attention's key
+// splits moved into its prologue (GemmArgs::ac_*): one launch less per layer where a launch is 3.4-4.4 us of a 53-us layer.
+// Same combine arithmetic, same MFMA order.  0 = launched, 1 = shape not covered (launch the combine, then launch_gemm), < 0 = error.
+int launch_gemm_acomb(const GemmArgs& g, hipStream_t st);
 // bf16 W [N][K] (row stride ldw) -> the fragment order GemmArgs::Wpk describes; N % 16 == 0, K % 32 == 0
 int launch_pack_gemm_weight(const void* W, int64_t ldw, int N, int K, void* out, hipStream_t st);
 // K-split factor that fills the chip for a bf16 decode GEMM (M <= DG_MAX_ROWS) whose consumer can add partial tiles; 1 = none.
 int decode_gemm_split(int N, int K);
 bool decode_gemm_split_ok(int K, int s);
+
+#if defined(__HIPCC__)
+// Element d of one (row, head) of the dense-K/V decode attention from its key splits' states pp[s][66] = (acc[64], m, l): the one
+// definition behind attn_decode_combine_kernel and the GEMM prologue that stands in for it.  All loads in flight at once (loads past
+// n_split are clamped to the last split and not used).
+__device__ __forceinline__ float attn_combine_splits(const float* __restrict__ pp, int n_split, int d) {
+    float ms[ACOMB_MAX_SPLIT], ls[ACOMB_MAX_SPLIT], as[ACOMB_MAX_SPLIT];
+#pragma unroll
+    for (int s = 0; s < ACOMB_MAX_SPLIT; ++s) {
+        const float* ps = pp + (s < n_split ? s : n_split - 1) * (HEAD_DIM + 2);
+        ms[s] = ps[HEAD_DIM]; ls[s] = ps[HEAD_DIM + 1]; as[s] = ps[d];
+    }
+    float M = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < ACOMB_MAX_SPLIT; ++s) if (s < n_split) M = fmaxf(M, ms[s]);
+    float L = 0.f, acc = 0.f;
+#pragma unroll
+    for (int s = 0; s < ACOMB_MAX_SPLIT; ++s) {
+        if (s < n_split) {
+            const float f = (ms[s] == -INFINITY) ? 0.f : exp2f((ms[s] - M) * 1.4426950408889634f);
+            L = fmaf(ls[s], f, L);
+            acc = fmaf(as[s], f, acc);
+        }
+    }
+    return acc / L;
+}
+#endif
 
 // ---- elementwise / norms ---------------------------------------------------------------------------
 int launch_layernorm(const float* x, const float* gamma, const float* beta, void* out, int out_dtype,
@@ -170,8 +206,10 @@ struct AttnArgs {
     int B = 0, H = 0;
     // split-key workspace (used when few (b,h) pairs would leave the chip idle)
     float* partial = nullptr; int n_split = 1;
+    bool defer_combine = false;          // dense K/V, n_split > 1: leave the key splits' states in `partial`; the caller's next kernel combines them
 };
 int launch_attn_decode(const AttnArgs& a, hipStream_t st);     // n_q == 1, waves split the keys
+int launch_attn_combine(const AttnArgs& a, hipStream_t st);    // the combine a deferred launch_attn_decode left out
 int launch_kv_append(const AttnArgs& a, hipStream_t st);       // prompt pass: write the k/v rows of a.B rows into the paged cache
 int launch_attn_rows(const AttnArgs& a, hipStream_t st);       // many queries, non-causal, dense K/V (fp32 encoder path)
 int launch_attn_flash_bf16(const AttnArgs& a, hipStream_t st); // MFMA flash attention, dense bf16 K/V, non-causal

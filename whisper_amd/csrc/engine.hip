@@ -1005,6 +1005,7 @@ static int decode_step_f32(wx_engine* e, int B, const SamplerArgs* sa, hipStream
 // G > 1 = prompt pass: the B rows are G consecutive forced positions (*d_pos ...) of B / G sequences, row r = sequence r / G,
 // position r % G.  Row-wise kernels do not care; self-attention appends all new k/v rows first and then reads the cache
 // causally per row, cross-attention shares a window's K/V stream among its G rows (the beam-search grouping).
+constexpr int ACOMB_FUSE_ROWS = 2;
 static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, float* apartial, bool prof_ok, hipStream_t st,
                               int G = 1, bool want_logits = true) {
     const int d = e->d, dtp = e->dt, T = e->T;
@@ -1057,6 +1058,7 @@ static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, floa
         WX_TRY(launch_reduce_layernorm(dx, gpartial, s_dd, L.self.bo, L.lnx_g, L.lnx_b, dxn, dtp, B, d, st));
         WX_TRY(split_gemm(dxn, d, L.xq, L.xq_pk, d, s_dd));
         const bool prof = prof_ok && e->prof_on && e->prof_used + 2 <= e->prof_events.size();
+        bool cross_out_done = false;
         if (e->xattn && e->beam_n <= 1) {
             // cross-attention on the encoder output itself (xattn.hip): q~ = s Wk_h^T q_h, one stream over E per row for
             // all heads, then the value projection of the context vectors.  Row r attends window (b0 + r) / G.
@@ -1080,11 +1082,26 @@ static int decode_layers_bf16(wx_engine* e, int b0, int B, float* gpartial, floa
             a.K = (char*)e->crossK + (cross_layer * i + cross_b0) * es; a.V = (char*)e->crossV + (cross_layer * i + cross_b0) * es;
             a.kv_sbh = (int64_t)T * HEAD_DIM; a.n_keys = T; a.kv_group = e->beam_n > 0 ? e->beam_n : G;
             a.O = datt; a.o_sb = d; a.B = B; a.H = e->Ht; a.n_split = n_split; a.partial = apartial;
+            // one or two rows: the key splits are combined in the prologue of the output projection (gemm.hip, launch_gemm_acomb)
+            // instead of a launch of their own (1.50 instead of 1.56 ms per position at one row; at four rows the prologue's loads
+            // cost more than the launch: 1.69 against 1.67).  WX_NO_FUSE_COMBINE=1: the stand-alone combine (read per eager pass / capture: tests toggle it)
+            a.defer_combine = n_split > 1 && B <= ACOMB_FUSE_ROWS && a.kv_group == 1 && dtp == DT_BF16 && L.xo_pk && getenv("WX_NO_FUSE_COMBINE") == nullptr;
             if (prof) HIP_TRY(hipEventRecord(e->prof_events[e->prof_used], st));
             WX_TRY(launch_attn_decode(a, st));
             if (prof) { HIP_TRY(hipEventRecord(e->prof_events[e->prof_used + 1], st)); e->prof_used += 2; }
+            if (a.defer_combine) {
+                GemmArgs g = gemm_basic(e, datt, d, L.xo, B, d, d);
+                g.Wpk = L.xo_pk;
+                g.n_split = s_dd; g.partial = gpartial;
+                if (s_dd == 1) { g.ep.out = gpartial; g.ep.out_dtype = DT_F32; g.ep.ldo = d; }
+                g.ac_partial = apartial; g.ac_nsplit = n_split; g.ac_H = e->Ht;
+                const int rc = launch_gemm_acomb(g, st);
+                if (rc < 0) return fail(WX_ERR_HIP, "launch_gemm_acomb");
+                if (rc == 0) cross_out_done = true;
+                else WX_TRY(launch_attn_combine(a, st));
+            }
         }
-        WX_TRY(split_gemm(datt, d, L.xo, L.xo_pk, d, s_dd));
+        if (!cross_out_done) WX_TRY(split_gemm(datt, d, L.xo, L.xo_pk, d, s_dd));
         WX_TRY(launch_reduce_layernorm(dx, gpartial, s_dd, L.xbo, L.ln2_g, L.ln2_b, dxn, dtp, B, d, st));
         {
             GemmArgs g = gemm_basic(e, dxn, d, L.w1, B, 4 * d, d);

@@ -879,6 +879,72 @@ __global__ __launch_bounds__(256) void gemm_bf16_decode_khalf_kernel(GemmArgs g)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// gemm_bf16_decode_kernel<1, CKS, 1, true> behind the dense-K/V decode cross-attention at <= ACOMB_ROWS rows, with the combine of
+// that attention's key splits in its prologue: column k of activation row m is element k % 64 of head k / 64, combined from the
+// splits' (acc, m, l) states by attn_combine_splits -- the function attn_decode_combine_kernel is made of -- rounded to bf16 where
+// that kernel stores it.  A K slice is whole heads (128, 256 or 320 columns), so a wave's 64 elements share one head's states; the
+// weight stream is issued first and the 1-5 elements per thread (18 four-byte loads each at six splits, L2 hits) land under it.
+// One launch less per layer: at one window a launch is 3.4-4.4 us of a 53-us layer whatever it does.
+// ---------------------------------------------------------------------------------------------------------
+template <int CKS>
+__global__ __launch_bounds__(256) void gemm_bf16_decode_acomb_kernel(GemmArgs g) {
+    constexpr int KB = CKS * 32, ROWB = KB * 2 + 32, EL = (ACOMB_ROWS * KB + 255) / 256;
+    __shared__ __attribute__((aligned(16))) char xs[ACOMB_ROWS * ROWB];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int gq = lane >> 4, r = lane & 15;
+    const int ntiles = (g.N + DG_BN - 1) / DG_BN;
+    const int tile = blockIdx.x % ntiles, split = blockIdx.x / ntiles;
+    const int n0 = tile * DG_BN + wid * 16;
+    const int kbeg = split * KB;
+    int u = n0 / 16; if (u > g.N / 16 - 1) u = g.N / 16 - 1;
+    const bf16* wp = reinterpret_cast<const bf16*>(g.Wpk) + ((int64_t)u * (g.K / 32) + kbeg / 32) * 512 + lane * 8;
+    bf16x8 w[CKS];
+#pragma unroll
+    for (int ks = 0; ks < CKS; ++ks) w[ks] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + ks * 512));
+    float val[EL];
+#pragma unroll
+    for (int j = 0; j < EL; ++j) {
+        int e = tid + j * 256; if (e > g.M * KB - 1) e = g.M * KB - 1;           // duplicates write identical bytes
+        const int row = e / KB, k = kbeg + e % KB;
+        val[j] = attn_combine_splits(g.ac_partial + ((int64_t)row * g.ac_H + (k >> 6)) * g.ac_nsplit * (HEAD_DIM + 2), g.ac_nsplit, k & 63);
+    }
+#pragma unroll
+    for (int j = 0; j < EL; ++j) {
+        int e = tid + j * 256; if (e > g.M * KB - 1) e = g.M * KB - 1;
+        *reinterpret_cast<bf16*>(xs + (e / KB) * ROWB + (e % KB) * 2) = (bf16)val[j];
+    }
+    __syncthreads();
+    const char* xr = xs + (r < g.M ? r : g.M - 1) * ROWB + gq * 16;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < CKS; ++ks) {
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xr + ks * 64);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks], xf, acc, 0, 0, 0);
+    }
+    if (g.n_split == 1) epilogue_store4(g.ep, r, n0 + gq * 4, acc, g.M, g.N);
+    else {
+        const int nn = n0 + gq * 4;
+        if (r < g.M && nn < g.N) *reinterpret_cast<f32x4*>(g.partial + ((int64_t)split * g.M + r) * g.N + nn) = acc;
+    }
+}
+
+int launch_gemm_acomb(const GemmArgs& g, hipStream_t st) {
+    if (g.in_dtype != DT_BF16 || !g.Wpk || g.M < 1 || g.M > ACOMB_ROWS || g.a_rows_per_batch != 0 || g.N % 16 || g.n_split < 1 || g.K % g.n_split) return 1;
+    if (!g.ac_partial || g.ac_nsplit < 2 || g.ac_nsplit > ACOMB_MAX_SPLIT || g.ac_H * HEAD_DIM != g.K) return 1;
+    if ((reinterpret_cast<uintptr_t>(g.Wpk) & 15) || (reinterpret_cast<uintptr_t>(g.ac_partial) & 3)) return -1;
+    if (g.n_split > 1 && (!g.partial || (reinterpret_cast<uintptr_t>(g.partial) & 15))) return -1;
+    if (g.n_split == 1 && !g.ep.out) return -1;
+    const int kb = g.K / g.n_split, blocks = ((g.N + DG_BN - 1) / DG_BN) * g.n_split;
+    switch (kb) {                                                   // one chunk per K slice, whole heads per slice
+        case 128: hipLaunchKernelGGL((gemm_bf16_decode_acomb_kernel<4>), dim3(blocks), dim3(256), 0, st, g); break;
+        case 256: hipLaunchKernelGGL((gemm_bf16_decode_acomb_kernel<8>), dim3(blocks), dim3(256), 0, st, g); break;
+        case 320: hipLaunchKernelGGL((gemm_bf16_decode_acomb_kernel<10>), dim3(blocks), dim3(256), 0, st, g); break;
+        default: return 1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 // 0 = launched, 1 = shape not covered (the caller takes the split-K path), < 0 = error
 int launch_gemm_khalf(const GemmArgs& g, hipStream_t st) {
     if (g.in_dtype != DT_BF16 || !g.Wpk || g.M <= 0 || g.M > DG_MAX_ROWS || g.a_rows_per_batch != 0 || g.N % 32 || g.K % 64) return 1;
