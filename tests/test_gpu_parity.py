@@ -279,6 +279,38 @@ def test_key_split_combine_inside_the_output_projection_is_bit_identical_bf16(mo
         eng.close()
 
 
+@pytest.mark.parametrize("name", ["micro", "tiny", "large1"])
+def test_self_attention_prefetch_depth_is_bit_identical_bf16(monkeypatch, name):
+    """Few decode rows: the self-attention kernel keeps four key iterations' loads in flight per wave (attention.hip, R = 4) instead
+    of one.  Same keys in the same order: logits at short and long positions, ids and log-probabilities are BIT-identical to
+    R = 1 (WX_SELF_ATTN_R1=1), eager and captured."""
+    import dataclasses
+    from whisper_amd.engine import WhisperEngine
+    dims = dataclasses.replace(ck.dims_for("large-v3"), n_audio_layer=1, n_text_layer=2) if name == "large1" else ck.dims_for(name)
+    sd = ck.synthetic_state_dict(dims, seed=0, eot_boost=3.0)
+    eng = WhisperEngine(dims, sd, precision="bf16", max_batch=3)
+    try:
+        mels = torch.stack([wo.log_mel_spectrogram(wo.varied_audio(s), dims.n_mels, padding=wo.N_SAMPLES)[:, :3000] for s in range(3)])
+        tok = eng.tok
+        rng = np.random.default_rng(3)
+        toks = torch.tensor(np.concatenate([np.tile([tok.sot, tok.lang(0), tok.transcribe, tok.no_timestamps], (3, 1)),
+                                            rng.integers(0, tok.eot, size=(3, 137))], axis=1))       # 141 positions: 1..5 iterations per wave
+        init = wo.initial_tokens(tok, 0)
+        eng.encode_windows(mels)
+        deep = eng.decoder_logits(toks).cpu()
+        a = eng.decode_greedy(3, init, max_new_tokens=40, use_graph=False)
+        g = eng.decode_greedy(3, init, max_new_tokens=40, use_graph=True)
+        monkeypatch.setenv("WX_SELF_ATTN_R1", "1")
+        one = eng.decoder_logits(toks).cpu()
+        b = eng.decode_greedy(3, init, max_new_tokens=40, use_graph=False)
+        monkeypatch.delenv("WX_SELF_ATTN_R1")
+        assert torch.isfinite(deep).all() and torch.equal(deep, one)
+        for x in (b, g):
+            assert torch.equal(a["tokens"], x["tokens"]) and torch.equal(a["sum_logprobs"], x["sum_logprobs"])
+    finally:
+        eng.close()
+
+
 def test_encoder_parity_256_tiles_bf16(models):
     """3 windows of a 256-wide model: M = 4500 rows (a ragged last tile) takes the 256x256 LDS-DMA GEMM kernel; the decoder
     runs its split-K GEMMs at K = 256 / 1024."""

@@ -108,7 +108,7 @@ __device__ __forceinline__ void load_head_rows(const AttnArgs& a, int b, int h, 
 // heads per workgroup, so a batch-64 launch is 320 workgroups that are all resident at once.  Round trip 1 fetches
 // everything that depends on no other load (position, page-table row, q/k/v partial tiles); round trip 2 is the K/V
 // stream: <= 448 keys, 64 keys (8 KiB K + 8 KiB V in bf16) per iteration in flight per wave.
-template <typename T, int NWH, int HPB = 4, int U = 8, bool GROUPED = false>
+template <typename T, int NWH, int HPB = 4, int U = 8, bool GROUPED = false, int R = 1>
 __global__ __launch_bounds__(64 * HPB * NWH) void attn_self_decode_kernel(AttnArgs a) {
     typedef Chunk<T> C;
     constexpr int EPL = C::EPL, LPK = HEAD_DIM / EPL, KPI = 64 / LPK, IT = KPI * U;
@@ -152,10 +152,14 @@ __global__ __launch_bounds__(64 * HPB * NWH) void attn_self_decode_kernel(AttnAr
 #pragma unroll
     for (int e = 0; e < EPL; ++e) o[e] = 0.f;
     const int total_it = (n_keys + IT - 1) / IT;
-    for (int it = kw; it < total_it; it += NWH) {
-        typename C::Raw kr[U], vr[U];
-        {
-            const int key0 = it * IT + grp;
+    // R iterations' loads are issued before the first of them is consumed (few rows: the launch is a handful of workgroups and
+    // every iteration would be one exposed round trip).  Iterations past the end are clamped duplicates whose scores are masked,
+    // so the online softmax sees the same keys in the same order for every R.
+    for (int it0 = kw; it0 < total_it; it0 += NWH * R) {
+        typename C::Raw kr[R][U], vr[R][U];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const int key0 = (it0 + rr * NWH) * IT + grp;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 int key = key0 + u * KPI;
@@ -163,41 +167,44 @@ __global__ __launch_bounds__(64 * HPB * NWH) void attn_self_decode_kernel(AttnAr
                 // the slot of position t_cur is being written by this launch: it is read (address valid, value ignored)
                 // and replaced by the register copy
                 const int64_t off = (((int64_t)s_pt[hs][key / PS] * a.H + h) * PS + key % PS) * HEAD_DIM + sub * EPL;
-                kr[u] = __builtin_nontemporal_load(reinterpret_cast<const typename C::Raw*>(Kp + off));
-                vr[u] = __builtin_nontemporal_load(reinterpret_cast<const typename C::Raw*>(Vp + off));
-                if (single && key == t_cur) { kr[u] = kn_r; vr[u] = vn_r; }
+                kr[rr][u] = __builtin_nontemporal_load(reinterpret_cast<const typename C::Raw*>(Kp + off));
+                vr[rr][u] = __builtin_nontemporal_load(reinterpret_cast<const typename C::Raw*>(Vp + off));
+                if (single && key == t_cur) { kr[rr][u] = kn_r; vr[rr][u] = vn_r; }
             }
         }
-        const int key0 = it * IT + grp;
-        float s[U];
-        float mt = -INFINITY;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            float kk[EPL];
-            C::unpack(kr[u], kk);
-            float d = 0.f;
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) d = fmaf(qf[e], kk[e], d);
-            d = group_sum<LPK>(d);
-            s[u] = (key0 + u * KPI < n_keys) ? d : -INFINITY;
-            mt = fmaxf(mt, s[u]);
-        }
-        if (mt > -INFINITY) {
-            const float mn = fmaxf(m, mt);
-            const float alpha = (m == -INFINITY) ? 0.f : exp2f((m - mn) * LOG2E);
-            l *= alpha;
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) o[e] *= alpha;
+        for (int rr = 0; rr < R; ++rr) {
+            const int key0 = (it0 + rr * NWH) * IT + grp;
+            float s[U];
+            float mt = -INFINITY;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const float p = exp2f((s[u] - mn) * LOG2E);   // exp2(-inf) = 0 for masked keys
-                l += p;
-                float vv[EPL];
-                C::unpack(vr[u], vv);
+                float kk[EPL];
+                C::unpack(kr[rr][u], kk);
+                float d = 0.f;
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) o[e] = fmaf(p, vv[e], o[e]);
+                for (int e = 0; e < EPL; ++e) d = fmaf(qf[e], kk[e], d);
+                d = group_sum<LPK>(d);
+                s[u] = (key0 + u * KPI < n_keys) ? d : -INFINITY;
+                mt = fmaxf(mt, s[u]);
             }
-            m = mn;
+            if (mt > -INFINITY) {
+                const float mn = fmaxf(m, mt);
+                const float alpha = (m == -INFINITY) ? 0.f : exp2f((m - mn) * LOG2E);
+                l *= alpha;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) o[e] *= alpha;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float p = exp2f((s[u] - mn) * LOG2E);   // exp2(-inf) = 0 for masked keys
+                    l += p;
+                    float vv[EPL];
+                    C::unpack(vr[rr][u], vv);
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) o[e] = fmaf(p, vv[e], o[e]);
+                }
+                m = mn;
+            }
         }
     }
 #pragma unroll
@@ -520,7 +527,10 @@ int launch_attn_decode(const AttnArgs& a, hipStream_t st) {
         // 6.1 / 9.4 / 17.4 / 27.7 us; pipelining the loads changes nothing once the iterations are this fine.  The grouped
         // (prompt pass) variant is a separate instantiation so the per-token step carries no index arithmetic for it.
         const dim3 grid2((a.B * a.H + 1) / 2);
-        if (a.dt == DT_BF16 && a.q_group == 1) hipLaunchKernelGGL((attn_self_decode_kernel<bf16, 2, 2, 2, false>), grid2, dim3(256), 0, st, a);
+        // few rows (<= 8 at 20 heads): four iterations' loads in flight per wave -- same keys, same order, same bits
+        const int few_r = getenv("WX_SELF_ATTN_R1") ? 0 : 160;     // (read per eager launch / capture: the test toggles it)
+        if (a.dt == DT_BF16 && a.q_group == 1 && a.B * a.H <= few_r) hipLaunchKernelGGL((attn_self_decode_kernel<bf16, 2, 2, 2, false, 4>), grid2, dim3(256), 0, st, a);
+        else if (a.dt == DT_BF16 && a.q_group == 1) hipLaunchKernelGGL((attn_self_decode_kernel<bf16, 2, 2, 2, false>), grid2, dim3(256), 0, st, a);
         else if (a.dt == DT_BF16) hipLaunchKernelGGL((attn_self_decode_kernel<bf16, 2, 2, 2, true>), grid2, dim3(256), 0, st, a);
         else if (a.q_group > 1) hipLaunchKernelGGL((attn_self_decode_kernel<float, 2, 4, 8, true>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((attn_self_decode_kernel<float, 2>), grid, dim3(512), 0, st, a);
