@@ -225,6 +225,16 @@ int32_t wx_cross_attention_form(wx_engine* e);
  * max_batch and n_lanes only */
 int32_t wx_cross_key_splits(wx_engine* e);
 
+/* Streams for batches in flight (whisper_amd/lanes.py; no counterpart in the reference, whose model serves one call at a time).
+ * Two streams that the HIP runtime maps onto ONE hardware queue run one after the other: with four lanes that costs a third of
+ * the throughput (profiles/r03_cu_share_and_hw_queues.txt, sections 2-3), and the mapping is the runtime's (GPU_MAX_HW_QUEUES, the
+ * streams made before).  wx_stream_spin launches one wave that idles for `microseconds` on `stream` (the current device), so a caller
+ * can time two streams against each other; wx_stream_create_exclusive makes a stream with a hardware queue of its own (a compute-unit
+ * mask naming every compute unit of `device`: such streams never share a queue); wx_stream_destroy destroys it. */
+int wx_stream_spin(void* stream, int32_t microseconds);
+int wx_stream_create_exclusive(int32_t device, void** out_stream);
+int wx_stream_destroy(void* stream);
+
 #ifdef __cplusplus
 }
 #endif

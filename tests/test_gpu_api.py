@@ -702,3 +702,19 @@ def test_temperature_fallback_redecodes_only_the_failed_files():
                        [(s["tokens"], s["start"], s["end"], 0.0) for s in base[i]["segments"]]
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("hw_queues", ["8", "2"])
+def test_lanes_get_a_hardware_queue_each(hw_queues):
+    """Two lane streams on one hardware queue take turns (a third of the throughput at four lanes), and with GPU_MAX_HW_QUEUES = 8
+    or 2 the runtime's mapping does put lanes together.  EngineLanes measures it (wx_stream_spin on two streams: 0.4 or 0.8 ms) and
+    gives a lane that shares another stream, then one with a queue of its own (wx_stream_create_exclusive).  Own process: the
+    variable is read when the HIP runtime starts."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES=hw_queues)
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "lane_queue_check.py")], env=env, capture_output=True, text=True, timeout=150)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rep = json.loads(out.stdout.strip().splitlines()[-1])
+    print(rep)
+    assert rep["pairs_still_taking_turns"] == []      # (rep["fixes"] says what it had to do: on this pool one or two lanes at 8, two at 2)

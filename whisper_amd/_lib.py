@@ -58,6 +58,9 @@ PROTOTYPES = {
     "wx_workspace_bytes": (c_i64, [c_vp]),
     "wx_cross_attention_form": (c_i32, [c_vp]),
     "wx_cross_key_splits": (c_i32, [c_vp]),
+    "wx_stream_spin": (c_i32, [c_vp, c_i32]),
+    "wx_stream_create_exclusive": (c_i32, [c_i32, ctypes.POINTER(c_vp)]),
+    "wx_stream_destroy": (c_i32, [c_vp]),
 }
 
 _lib = None

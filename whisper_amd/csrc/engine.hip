@@ -1470,4 +1470,48 @@ int64_t wx_workspace_bytes(wx_engine* e) { return e ? e->work_bytes : 0; }
 int32_t wx_cross_attention_form(wx_engine* e) { return e && e->xattn ? 1 : 0; }
 int32_t wx_cross_key_splits(wx_engine* e) { return !e || !e->finalized ? 0 : e->xattn ? e->x_split : cross_attn_key_split(e); }
 
+// one wave that does nothing for `ns` nanoseconds of the GPU's constant-rate clock (100 MHz on gfx950) and leaves: every lane reaches the exit
+__global__ void spin_kernel(long long ticks) {
+    const long long t0 = (long long)__builtin_readcyclecounter();
+    (void)t0;
+    const unsigned long long r0 = wall_clock64();
+    while ((long long)(wall_clock64() - r0) < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+int wx_stream_spin(void* stream, int32_t microseconds) {
+    if (microseconds < 1 || microseconds > 100000) return fail(WX_ERR_INVALID, "1..100000 microseconds");
+    int dev = 0, rate_khz = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, dev));
+    if (rate_khz <= 0) rate_khz = 100000;
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)microseconds * rate_khz / 1000);
+    HIP_TRY(hipGetLastError());
+    return WX_OK;
+}
+
+int wx_stream_create_exclusive(int32_t device, void** out_stream) {
+    if (!out_stream) return fail(WX_ERR_INVALID, "null argument");
+    int prev = 0, n_dev = 0;
+    HIP_TRY(hipGetDeviceCount(&n_dev));
+    if (device < 0 || device >= n_dev) return fail(WX_ERR_INVALID, "no such device");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    std::vector<uint32_t> mask((size_t)(prop.multiProcessorCount + 31) / 32, 0u);
+    for (int i = 0; i < prop.multiProcessorCount; ++i) mask[(size_t)i >> 5] |= 1u << (i & 31);
+    HIP_TRY(hipGetDevice(&prev));
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = nullptr;
+    const hipError_t ce = hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data());
+    (void)hipSetDevice(prev);
+    if (ce != hipSuccess) return fail(WX_ERR_HIP, std::string("hipExtStreamCreateWithCUMask: ") + hipGetErrorString(ce));
+    *out_stream = (void*)st;
+    return WX_OK;
+}
+
+int wx_stream_destroy(void* stream) {
+    if (!stream) return WX_OK;
+    HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return WX_OK;
+}
+
 }  // extern "C"

@@ -23,8 +23,10 @@ makes batches, and therefore lanes, possible.
 from __future__ import annotations
 
 import logging
+import os
 import queue
 import threading
+import time
 from typing import Callable, Dict, List, Optional, Sequence
 
 import torch
@@ -37,6 +39,7 @@ class _Lane:
     def __init__(self, engine, index: int):
         self.engine = engine
         self.index = index
+        self.exclusive_stream = None      # raw handle of a wx_stream_create_exclusive stream, when the lane needed one
         # (a duck-typed engine on a CPU device -- the host-logic tests' stand-in -- gets a thread and no stream)
         self.stream = torch.cuda.Stream(device=engine.torch_device) if engine.torch_device.type == "cuda" else None
         self.jobs: "queue.Queue" = queue.Queue()
@@ -99,6 +102,54 @@ class EngineLanes:
                 e.encode_gate = gate
         self._lanes = [_Lane(e, i) for i, e in enumerate(engines)]
         self._next = 0
+        self.queue_fixes: List[str] = []
+        if len(engines) > 1 and e0.torch_device.type == "cuda" and os.environ.get("WX_LANES_NO_QUEUE_CHECK") != "1":
+            self._separate_hardware_queues()
+
+    # Two lane streams that the HIP runtime put on ONE hardware queue run one after the other -- a third of the throughput at four
+    # lanes -- and which streams share is the runtime's business (GPU_MAX_HW_QUEUES = 7 or 8 pairs lanes 0/2 and 1/3; the default 4
+    # does not; profiles/r03_cu_share_and_hw_queues.txt sections 2-3).  So it is measured: a wave that idles for 400 us on each of
+    # two streams takes 0.4 ms when they have a queue each and 0.8 ms when they share one.  A lane that shares gets another stream
+    # of the runtime's pool, then one with a queue of its own (wx_stream_create_exclusive).
+    def _serialised(self, a, b, lib, us: int = 400) -> bool:
+        import ctypes
+        best = None
+        for _ in range(2):                                   # (the shorter of two trials: a host hiccup is not a shared queue)
+            a.synchronize(); b.synchronize()
+            t0 = time.perf_counter()
+            for st in (a, b):
+                rc = lib.wx_stream_spin(ctypes.c_void_p(st.cuda_stream), us)
+                if rc != 0:
+                    return False
+            a.synchronize(); b.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return best > 1.6 * us * 1e-6
+
+    def _separate_hardware_queues(self) -> None:
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        dev = self._lanes[0].engine.torch_device
+        with torch.cuda.device(dev):
+            for j in range(1, len(self._lanes)):
+                lane = self._lanes[j]
+                for attempt in range(3):
+                    if not any(self._serialised(self._lanes[i].stream, lane.stream, lib) for i in range(j)):
+                        break
+                    if attempt == 0:
+                        lane.stream = torch.cuda.Stream(device=dev)
+                        self.queue_fixes.append(f"lane {j}: shared a hardware queue with an earlier lane; took another stream")
+                    elif attempt == 1:
+                        raw = ctypes.c_void_p()
+                        _lib.check(lib.wx_stream_create_exclusive(dev.index or 0, ctypes.byref(raw)), "wx_stream_create_exclusive")
+                        lane.exclusive_stream = raw
+                        lane.stream = torch.cuda.ExternalStream(raw.value, device=dev)
+                        self.queue_fixes.append(f"lane {j}: still shared; made a stream with a hardware queue of its own")
+                    else:
+                        log.warning("lane %d still shares a hardware queue with another lane: its batches will take turns with that lane's", j)
+        for msg in self.queue_fixes:
+            log.info(msg)
 
     @classmethod
     def create(cls, make_engine: Callable[[int], object], n_lanes: int, share_weights: bool = True,
@@ -188,6 +239,10 @@ class EngineLanes:
                 log.error("lane %d did not finish; its engine is left alive (leaked) rather than destroyed under a running job", ln.index)
                 continue
             ln.engine.close()
+            if ln.exclusive_stream is not None:
+                from . import _lib
+                _lib.load().wx_stream_destroy(ln.exclusive_stream)
+                ln.exclusive_stream = None
         self._lanes = []
 
     def __enter__(self):
