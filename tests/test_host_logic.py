@@ -337,3 +337,49 @@ def test_engine_lanes_deal_batches_in_order_and_pass_errors_on():
         EngineLanes([Fake("a"), Fake("b", max_batch=4)])
     with pytest.raises(ValueError):
         EngineLanes([])
+
+
+def test_engine_lanes_share_one_encode_gate():
+    """The lanes of a GPU run their encoders one at a time: EngineLanes hands every engine that has an ``encode_gate`` slot the SAME
+    lock (engines take it around ``encode()``, whisper_amd/engine.py); stand-ins without the slot are left alone, and
+    ``one_encoder_at_a_time=False`` leaves real engines ungated.  Two lanes that encode at once overlap without the gate and never
+    with it."""
+    import threading
+    import time
+    import torch
+    from whisper_amd.lanes import EngineLanes
+
+    class Fake:
+        def __init__(self):
+            self.max_batch, self.dims, self.precision, self.torch_device = 2, "dims", "fp32", torch.device("cpu")
+            self.encode_gate = None
+            self.inside = []
+
+        def encode(self, log):
+            gate = self.encode_gate
+            if gate is not None:
+                gate.acquire()
+            try:
+                log.append(("in", time.perf_counter())); time.sleep(0.05); log.append(("out", time.perf_counter()))
+            finally:
+                if gate is not None:
+                    gate.release()
+
+        def close(self):
+            pass
+
+    def overlapped(lanes):
+        log = []
+        lanes.map(lambda e, _: e.encode(log), [0, 1])
+        log.sort(key=lambda x: x[1])
+        return [k for k, _ in log] != ["in", "out", "in", "out"]
+
+    with EngineLanes([Fake(), Fake()]) as lanes:
+        gates = {id(e.encode_gate) for e in lanes.engines}
+        assert len(gates) == 1 and lanes.engines[0].encode_gate is not None
+        assert not overlapped(lanes)
+    with EngineLanes([Fake(), Fake()], one_encoder_at_a_time=False) as lanes:
+        assert all(e.encode_gate is None for e in lanes.engines)
+        assert overlapped(lanes)
+    with EngineLanes([Fake()]) as lanes:                      # one lane: nothing to keep apart
+        assert lanes.engines[0].encode_gate is None
